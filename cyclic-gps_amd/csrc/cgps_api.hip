@@ -1,0 +1,431 @@
+// C-ABI entry points of libcgps (see include/cgps.h).  Host code only decides
+// sizes/offsets and enqueues kernels on the caller's stream; nothing here
+// allocates, copies to the host or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <type_traits>
+
+#include "../../include/cgps.h"
+#include "cgps_level.h"
+#include "cgps_tile.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CGPS_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  return CGPS_OK;
+}
+
+template <typename Fn>
+int dispatch(int dtype, int d, Fn&& fn) {
+#define CGPS_CASE(DV)                                                        \
+  case DV:                                                                   \
+    return dtype == CGPS_F32 ? fn(float{}, std::integral_constant<int, DV>{}) \
+                             : fn(double{}, std::integral_constant<int, DV>{});
+  if (dtype != CGPS_F32 && dtype != CGPS_F64) return fail(CGPS_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
+  switch (d) {
+    CGPS_CASE(1) CGPS_CASE(2) CGPS_CASE(3) CGPS_CASE(4) CGPS_CASE(5) CGPS_CASE(6) CGPS_CASE(7) CGPS_CASE(8)
+    default:
+      return fail(CGPS_ERR_UNSUPPORTED, "block size d=%d outside 1..8", d);
+  }
+#undef CGPS_CASE
+}
+
+struct Layout {
+  int nlevels;
+  int64_t ms[CGPS_MAX_LEVELS], offD[CGPS_MAX_LEVELS + 1], offF[CGPS_MAX_LEVELS + 1], offG[CGPS_MAX_LEVELS + 1];
+};
+
+void make_layout(int64_t N, Layout& L) {
+  int l = 0;
+  int64_t m = N, oD = 0, oF = 0, oG = 0;
+  for (;;) {
+    L.ms[l] = m;
+    L.offD[l] = oD; L.offF[l] = oF; L.offG[l] = oG;
+    oD += (m + 1) / 2; oF += m / 2; oG += (m - 1) / 2;
+    ++l;
+    if (m == 1) break;
+    m /= 2;
+  }
+  L.nlevels = l;
+  L.offD[l] = oD; L.offF[l] = oF; L.offG[l] = oG;
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int64_t level_blocks(int64_t m) { return ((m + 1) / 2 + cgps::LEVEL_THREADS - 1) / cgps::LEVEL_THREADS; }
+
+// workspace carve-up shared by the level-wise paths
+struct LevelWs {
+  size_t partial_off, partial_bytes;  // [total blocks][2] doubles
+  size_t a_off, b_off;                // ping-pong level buffers
+  int64_t capA, capB;                 // rows
+  size_t total;
+};
+
+LevelWs level_ws(int64_t N, int d, size_t s, bool with_mats, bool with_vec) {
+  LevelWs w{};
+  Layout L;
+  make_layout(N, L);
+  int64_t nb = 0;
+  for (int l = 0; l < L.nlevels; ++l) nb += level_blocks(L.ms[l]);
+  w.partial_off = 0;
+  w.partial_bytes = align_up((size_t)(nb + 1) * 16);
+  w.capA = N / 2 + 1;
+  w.capB = N / 4 + 1;
+  size_t per_row = (with_mats ? 2 * (size_t)d * d : 0) + (with_vec ? (size_t)d : 0);
+  w.a_off = w.partial_bytes;
+  w.b_off = w.a_off + align_up(per_row * s * w.capA);
+  w.total = w.b_off + align_up(per_row * s * w.capB);
+  return w;
+}
+
+template <typename T>
+struct LevelBuf {
+  T *R, *O, *y;
+};
+template <typename T>
+LevelBuf<T> carve(char* base, int64_t cap, int d, bool with_mats, bool with_vec) {
+  LevelBuf<T> b{nullptr, nullptr, nullptr};
+  T* p = reinterpret_cast<T*>(base);
+  if (with_mats) { b.R = p; p += cap * d * d; b.O = p; p += cap * d * d; }
+  if (with_vec) b.y = p;
+  return b;
+}
+
+// ---------------------------------------------------------------------------------
+template <typename T, int D>
+int run_levelwise(const T* Rs, const T* Os, const T* x, int64_t N, T* Dp, T* Fp, T* Gp, T* xcrr,
+                  char* ws, size_t ws_bytes, double* out2, int* info, hipStream_t st) {
+  const bool rhs = (x != nullptr), emit = (Dp != nullptr);
+  LevelWs w = level_ws(N, D, sizeof(T), true, rhs);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  LevelBuf<T> bufs[2] = {carve<T>(ws + w.a_off, w.capA, D, true, rhs), carve<T>(ws + w.b_off, w.capB, D, true, rhs)};
+  hipMemsetAsync(info, 0, sizeof(int), st);
+  const T *R = Rs, *O = Os, *y = x;
+  int64_t pb = 0;
+  for (int l = 0; l < L.nlevels; ++l) {
+    const int64_t n = L.ms[l];
+    const int64_t nb = level_blocks(n);
+    LevelBuf<T>& nx = bufs[l & 1];
+    T* Dk = emit ? Dp + L.offD[l] * D * D : nullptr;
+    T* Fk = emit ? Fp + L.offF[l] * D * D : nullptr;
+    T* Gk = emit ? Gp + L.offG[l] * D * D : nullptr;
+    T* xk = (emit && rhs && xcrr) ? xcrr + L.offD[l] * D : nullptr;
+    dim3 grid((unsigned)nb), block(cgps::LEVEL_THREADS);
+    if (l == 0 && g_prof_start) hipEventRecord(g_prof_start, st);
+    if (emit && rhs)
+      hipLaunchKernelGGL((cgps::level_kernel<T, D, true, true>), grid, block, 0, st, R, O, y, n, l, Dk, Fk, Gk, xk,
+                         nx.R, nx.O, nx.y, partial + 2 * pb, info);
+    else if (emit)
+      hipLaunchKernelGGL((cgps::level_kernel<T, D, true, false>), grid, block, 0, st, R, O, y, n, l, Dk, Fk, Gk, xk,
+                         nx.R, nx.O, nx.y, partial + 2 * pb, info);
+    else if (rhs)
+      hipLaunchKernelGGL((cgps::level_kernel<T, D, false, true>), grid, block, 0, st, R, O, y, n, l, Dk, Fk, Gk, xk,
+                         nx.R, nx.O, nx.y, partial + 2 * pb, info);
+    else
+      hipLaunchKernelGGL((cgps::level_kernel<T, D, false, false>), grid, block, 0, st, R, O, y, n, l, Dk, Fk, Gk, xk,
+                         nx.R, nx.O, nx.y, partial + 2 * pb, info);
+    if (l == 0 && g_prof_stop) {
+      hipEventRecord(g_prof_stop, st);
+      g_prof_start = g_prof_stop = nullptr;
+    }
+    pb += nb;
+    R = nx.R; O = nx.O; y = nx.y;
+  }
+  if (out2) hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, out2);
+  return check_launch("levelwise reduction");
+}
+
+template <typename T, int D>
+int run_halfsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws, size_t ws_bytes,
+                  double* mahal_out, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
+  const T* y = y0;
+  int64_t pb = 0;
+  for (int l = 0; l < L.nlevels; ++l) {
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* yn = bufs[l & 1];
+    hipLaunchKernelGGL((cgps::halfsolve_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D, y, n,
+                       xcrr + L.offD[l] * D, yn, partial + 2 * pb);
+    pb += nb;
+    y = yn;
+  }
+  if (mahal_out) {
+    double* tmp = partial + 2 * pb;  // one spare slot was reserved
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, tmp);
+    hipMemcpyAsync(mahal_out, tmp, sizeof(double), hipMemcpyDeviceToDevice, st);
+  }
+  return check_launch("halfsolve");
+}
+
+template <typename T, int D>
+int run_backsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  // both ping-pong buffers must hold a level-1 vector here
+  const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);
+  if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+  Layout L;
+  make_layout(N, L);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
+                reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};
+  const T* xo = nullptr;
+  for (int l = L.nlevels - 1; l >= 0; --l) {
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* X = (l == 0) ? x : bufs[l & 1];
+    hipLaunchKernelGGL((cgps::backsolve_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D,
+                       ycrr + L.offD[l] * D, xo, n, X);
+    xo = X;
+  }
+  return check_launch("backsolve");
+}
+
+template <typename T, int D>
+int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, char* ws, size_t ws_bytes,
+                hipStream_t st) {
+  const int64_t cap = N / 2 + 1;
+  const size_t one = align_up((size_t)2 * D * D * sizeof(T) * cap);
+  if (ws_bytes < 2 * one) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, 2 * one);
+  Layout L;
+  make_layout(N, L);
+  T* bufs[2] = {reinterpret_cast<T*>(ws), reinterpret_cast<T*>(ws + one)};
+  const T *Sdc = nullptr, *Soc = nullptr;
+  for (int l = L.nlevels - 1; l >= 0; --l) {
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* od = (l == 0) ? Sd : bufs[l & 1];
+    T* oo = (l == 0) ? So : bufs[l & 1] + cap * D * D;
+    hipLaunchKernelGGL((cgps::inverse_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D, Sdc, Soc, n, od, oo);
+    Sdc = od; Soc = oo;
+  }
+  return check_launch("inverse_blocks");
+}
+
+bool bad_common(int64_t N, int d) { return N < 1 || d < 1; }
+
+}  // namespace
+
+extern "C" {
+
+int cgps_version(void) { return CGPS_VERSION; }
+const char* cgps_last_error(void) { return g_err; }
+
+int cgps_profile_next_call(void* start_event, void* stop_event) {
+  g_prof_start = (hipEvent_t)start_event;
+  g_prof_stop = (hipEvent_t)stop_event;
+  return CGPS_OK;
+}
+
+int cgps_level_layout(int64_t N, int* nlevels, int64_t* ms, int64_t* offD, int64_t* offF, int64_t* offG) {
+  if (N < 1 || !nlevels) return fail(CGPS_ERR_ARG, "cgps_level_layout: N must be >= 1");
+  Layout L;
+  make_layout(N, L);
+  *nlevels = L.nlevels;
+  for (int l = 0; l < L.nlevels; ++l)
+    if (ms) ms[l] = L.ms[l];
+  for (int l = 0; l <= L.nlevels; ++l) {
+    if (offD) offD[l] = L.offD[l];
+    if (offF) offF[l] = L.offF[l];
+    if (offG) offG[l] = L.offG[l];
+  }
+  return CGPS_OK;
+}
+
+int cgps_workspace_bytes(int64_t N, int d, int dtype, int op, size_t* bytes) {
+  if (bad_common(N, d) || !bytes) return fail(CGPS_ERR_ARG, "cgps_workspace_bytes: bad argument");
+  if (d > 8) return fail(CGPS_ERR_UNSUPPORTED, "block size d=%d outside 1..8", d);
+  if (dtype != CGPS_F32 && dtype != CGPS_F64) return fail(CGPS_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
+  const size_t s = dtype == CGPS_F32 ? 4 : 8;
+  const int64_t capA = N / 2 + 1;
+  switch (op) {
+    case CGPS_OP_MAHAL_LOGDET_LEVELWISE:
+      *bytes = level_ws(N, d, s, true, true).total;
+      return CGPS_OK;
+    case CGPS_OP_MAHAL_LOGDET: {
+      size_t a = level_ws(N, d, s, true, true).total;
+      size_t b = cgps::tile_ws_bytes(N, d, s);
+      *bytes = a > b ? a : b;
+      return CGPS_OK;
+    }
+    case CGPS_OP_DECOMPOSE:
+      *bytes = level_ws(N, d, s, true, false).total;
+      return CGPS_OK;
+    case CGPS_OP_HALFSOLVE:
+      *bytes = level_ws(N, d, s, false, true).total;
+      return CGPS_OK;
+    case CGPS_OP_BACKSOLVE:
+    case CGPS_OP_SOLVE: {
+      LevelWs w = level_ws(N, d, s, false, true);
+      size_t back = w.partial_bytes + 2 * align_up((size_t)d * s * capA);
+      size_t crr = (op == CGPS_OP_SOLVE) ? align_up((size_t)N * d * s) : 0;
+      size_t m = w.total > back ? w.total : back;
+      *bytes = crr + m;
+      return CGPS_OK;
+    }
+    case CGPS_OP_LOGDET_FACTOR:
+      *bytes = align_up((size_t)(1024 + 2) * 16);
+      return CGPS_OK;
+    case CGPS_OP_INVERSE_BLOCKS:
+      *bytes = 2 * align_up((size_t)2 * d * d * s * capA);
+      return CGPS_OK;
+    default:
+      return fail(CGPS_ERR_ARG, "cgps_workspace_bytes: unknown op %d", op);
+  }
+}
+
+int cgps_mahal_logdet_levelwise(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype, void* ws,
+                                size_t ws_bytes, double* out2, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !x || !ws || !out2 || !info)
+    return fail(CGPS_ERR_ARG, "cgps_mahal_logdet: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_levelwise<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, nullptr, nullptr, nullptr, nullptr,
+                               (char*)ws, ws_bytes, out2, info, (hipStream_t)stream);
+  });
+}
+
+int cgps_mahal_logdet(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype, void* ws,
+                      size_t ws_bytes, double* out2, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !x || !ws || !out2 || !info)
+    return fail(CGPS_ERR_ARG, "cgps_mahal_logdet: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if (!cgps::tile_supported<T, D>())
+      return run_levelwise<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, nullptr, nullptr, nullptr, nullptr,
+                                 (char*)ws, ws_bytes, out2, info, (hipStream_t)stream);
+    int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, (char*)ws, ws_bytes, out2,
+                                               info, (hipStream_t)stream);
+    if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_mahal_logdet");
+    return check_launch("tile reduction");
+  });
+}
+
+int cgps_decompose_step(const void* Rs, const void* Os, int64_t n, int d, int dtype, void* Dk, void* Fk, void* Gk,
+                        void* Rn, void* On, int* info, void* stream) {
+  if (n < 2 || d < 1 || !Rs || !Os || !Dk || !Fk || !Rn || !info || (n > 2 && (!Gk)) || (n > 3 && !On))
+    return fail(CGPS_ERR_ARG, "cgps_decompose_step: null pointer or n < 2");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(info, 0, sizeof(int), st);
+    const int64_t nb = level_blocks(n);
+    hipLaunchKernelGGL((cgps::level_kernel<T, D, true, false>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       (const T*)Rs, (const T*)Os, (const T*)nullptr, n, 0, (T*)Dk, (T*)Fk, (T*)Gk, (T*)nullptr,
+                       (T*)Rn, (T*)On, (T*)nullptr, (double*)nullptr, info);
+    return check_launch("decompose_step");
+  });
+}
+
+int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, void* Dp, void* Fp, void* Gp, void* ws,
+                   size_t ws_bytes, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !Dp || !Fp || !Gp || !ws || !info)
+    return fail(CGPS_ERR_ARG, "cgps_decompose: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_levelwise<T, D>((const T*)Rs, (const T*)Os, nullptr, N, (T*)Dp, (T*)Fp, (T*)Gp, nullptr, (char*)ws,
+                               ws_bytes, nullptr, info, (hipStream_t)stream);
+  });
+}
+
+int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y,
+                   void* xcrr, void* ws, size_t ws_bytes, double* mahal_out, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !xcrr || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_halfsolve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, (T*)xcrr, (char*)ws, ws_bytes,
+                               mahal_out, (hipStream_t)stream);
+  });
+}
+
+int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* ycrr,
+                   void* x, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !ycrr || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_backsolve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)ycrr, (T*)x, (char*)ws, ws_bytes,
+                               (hipStream_t)stream);
+  });
+}
+
+int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y, void* x,
+               void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_solve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const size_t crr = align_up((size_t)N * D * sizeof(T));
+    if (ws_bytes < crr) return fail(CGPS_ERR_ARG, "workspace too small");
+    T* xcrr = (T*)ws;
+    int rc = run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, xcrr, (char*)ws + crr,
+                                 ws_bytes - crr, nullptr, (hipStream_t)stream);
+    if (rc != CGPS_OK) return rc;
+    return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, xcrr, (T*)x, (char*)ws + crr,
+                               ws_bytes - crr, (hipStream_t)stream);
+  });
+}
+
+int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype, void* ws, size_t ws_bytes, double* out,
+                       void* stream) {
+  if (bad_common(N, d) || !Dp || !ws || !out) return fail(CGPS_ERR_ARG, "cgps_logdet_factor: null pointer or N < 1");
+  if (ws_bytes < (size_t)(1024 + 2) * 16) return fail(CGPS_ERR_ARG, "workspace too small");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)ws;
+    int64_t nb = (N * D + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL((cgps::logdiag_kernel<T, D>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)Dp, N, partial);
+    double* tmp = partial + 2 * nb;
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, nb, tmp);
+    hipMemcpyAsync(out, tmp + 1, sizeof(double), hipMemcpyDeviceToDevice, st);
+    return check_launch("logdet_factor");
+  });
+}
+
+int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, void* Sd, void* So,
+                        void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !Sd || (N > 1 && !So) || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_inverse_blocks: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_inverse<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (T*)Sd, (T*)So, (char*)ws, ws_bytes,
+                             (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+"""ctypes binding of libcgps.so (C ABI: include/cgps.h).
+
+The library is the product: if it is missing this module raises, it never falls
+back to a CPU or torch implementation.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CGPS_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libcgps.so"))
+
+F32, F64 = 0, 1
+OP_MAHAL_LOGDET, OP_DECOMPOSE, OP_HALFSOLVE, OP_BACKSOLVE, OP_SOLVE, OP_LOGDET_FACTOR, OP_INVERSE_BLOCKS, \
+    OP_MAHAL_LOGDET_LEVELWISE = range(8)
+MAX_LEVELS = 64
+
+_lib = None
+
+_vp, _i64, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_SIGNATURES = {
+    "cgps_version": (_int, []),
+    "cgps_last_error": (ctypes.c_char_p, []),
+    "cgps_profile_next_call": (_int, [_vp, _vp]),
+    "cgps_level_layout": (_int, [_i64, ctypes.POINTER(_int)] + [ctypes.POINTER(_i64)] * 4),
+    "cgps_workspace_bytes": (_int, [_i64, _int, _int, _int, ctypes.POINTER(_sz)]),
+    "cgps_mahal_logdet": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),
+    "cgps_mahal_logdet_levelwise": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),
+    "cgps_decompose_step": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cgps_decompose": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cgps_halfsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cgps_backsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cgps_solve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cgps_logdet_factor": (_int, [_vp, _i64, _int, _int, _vp, _sz, _vp, _vp]),
+    "cgps_inverse_blocks": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class CgpsError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libcgps.so once; raise loudly when it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CgpsError(
+                "libcgps.so not found at %s -- build it with `python __graft_entry__.py` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        # libcgps needs libamdhip64.so.7; torch ships its own copy under that soname and must be
+        # the one runtime in the process (its streams/pointers are what we are handed), so make
+        # sure it is resident before the loader resolves our dependency.
+        rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise CgpsError("libcgps error %d: %s" % (rc, lib().cgps_last_error().decode()))
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.float64:
+        return F64
+    raise TypeError("cyclic reduction supports float32 / float64 blocks, got %s" % dt)
+
+
+def ptr(t):
+    return None if t is None or t.numel() == 0 else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def level_layout(N):
+    """(ms, offD, offF, offG) python lists; offsets have one extra entry (the total)."""
+    n = _int(0)
+    arrs = [(ctypes.c_int64 * (MAX_LEVELS + 1))() for _ in range(4)]
+    check(lib().cgps_level_layout(N, ctypes.byref(n), *arrs))
+    L = n.value
+    return (list(arrs[0][:L]), list(arrs[1][:L + 1]), list(arrs[2][:L + 1]), list(arrs[3][:L + 1]))
+
+
+_ws_cache = {}
+
+
+def workspace(N, d, dt, op, device):
+    """A cached scratch tensor of the size the library asks for (torch owns the memory)."""
+    b = _sz(0)
+    check(lib().cgps_workspace_bytes(N, d, dtype_code(dt), op, ctypes.byref(b)))
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    cur = _ws_cache.get(key)
+    if cur is None or cur.numel() < b.value:
+        cur = torch.empty(max(b.value, 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = cur
+    return cur, b.value

@@ -1,0 +1,124 @@
+/* libcgps -- C ABI of the MI355X (gfx950) block-tridiagonal cyclic-reduction library.
+ *
+ * The reference (cunningham-lab/cyclic-gps) has no FFI: its boundary for this
+ * path is the Python module cyclic_gps/cyclic_reduction.py.  Each entry point
+ * below is what a ctypes binding for one function of that module calls; the
+ * function it replaces is cited as file:line (relative to the reference root).
+ * The Python mirror of the module lives in cyclic-gps_amd/cyclic_gps/.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (hipMalloc / torch CUDA tensors),
+ *     C-contiguous, batch-major: Rs[N][d][d], Os[N-1][d][d], vectors [N][d].
+ *     O_i is the LOWER off-diagonal block J[i+1][i].
+ *   - The library never allocates, frees or synchronises: the caller passes a
+ *     scratch buffer of cgps_workspace_bytes() bytes, a HIP stream (hipStream_t
+ *     as void*; NULL = default stream), and every call is asynchronous.
+ *   - dtype: CGPS_F32 / CGPS_F64.  1 <= d <= 8.
+ *   - Return value: CGPS_OK, or an error code; cgps_last_error() gives a
+ *     thread-local message.
+ *   - Non-positive-definite blocks are reported through the device word
+ *     `info` (like torch.linalg.cholesky_ex): 0 = fine, otherwise 1 + the
+ *     smallest original block-row index whose pivot was not positive.  The
+ *     library zeroes it at the start of the call.
+ *   - Factor storage ("packed factor"): the reference's decomp = (ms, Ds, Fs, Gs)
+ *     (cyclic_reduction.py:287-309) with the per-level tensors concatenated in
+ *     level order: Dp[sum ceil(m_l/2)] = Dp[N], Fp[sum floor(m_l/2)],
+ *     Gp[sum floor((m_l-1)/2)], m_0 = N, m_{l+1} = floor(m_l/2).  Allocate N
+ *     blocks for each.  cgps_level_layout() returns the sizes and offsets.
+ *     A vector in "CRR layout" (halfsolve output, cyclic_reduction.py:312-338)
+ *     uses the Dp offsets: [N][d].
+ */
+#ifndef CGPS_H
+#define CGPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGPS_VERSION 100
+
+enum { CGPS_F32 = 0, CGPS_F64 = 1 };
+
+enum {
+  CGPS_OK = 0,
+  CGPS_ERR_ARG = 1,        /* bad argument (null pointer, N < 1, workspace too small ...) */
+  CGPS_ERR_HIP = 2,        /* HIP runtime error at launch */
+  CGPS_ERR_UNSUPPORTED = 3 /* d or dtype outside the compiled range */
+};
+
+/* which operation a workspace is sized for */
+enum {
+  CGPS_OP_MAHAL_LOGDET = 0,
+  CGPS_OP_DECOMPOSE = 1,
+  CGPS_OP_HALFSOLVE = 2,
+  CGPS_OP_BACKSOLVE = 3,
+  CGPS_OP_SOLVE = 4,
+  CGPS_OP_LOGDET_FACTOR = 5,
+  CGPS_OP_INVERSE_BLOCKS = 6,
+  CGPS_OP_MAHAL_LOGDET_LEVELWISE = 7
+};
+
+#define CGPS_MAX_LEVELS 64
+
+int cgps_version(void);
+const char* cgps_last_error(void);
+
+/* Level sizes and packed-factor offsets for N block rows (host-side arithmetic only).
+ * ms[l] = rows at level l (ms[nlevels-1] == 1); offD/offF/offG[l] = first block of
+ * level l in Dp/Fp/Gp; arrays must hold CGPS_MAX_LEVELS entries (offsets: +1 for the total). */
+int cgps_level_layout(int64_t N, int* nlevels, int64_t* ms, int64_t* offD, int64_t* offF, int64_t* offG);
+
+int cgps_workspace_bytes(int64_t N, int d, int dtype, int op, size_t* bytes);
+
+/* mahal_and_det(Rs, Os, x) -> (x^T J^-1 x, log|J|)        cyclic_reduction.py:380-438
+ * out2[0] = mahal, out2[1] = logdet (device doubles, accumulated in fp64 for both dtypes). */
+int cgps_mahal_logdet(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype,
+                      void* ws, size_t ws_bytes, double* out2, int* info, void* stream);
+/* same result, one kernel launch per reduction level (simple form, kept as cross-check) */
+int cgps_mahal_logdet_levelwise(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype,
+                                void* ws, size_t ws_bytes, double* out2, int* info, void* stream);
+
+/* decompose_step(Rs, Os) -> (n, D, F, G), (R', O')           cyclic_reduction.py:203-259
+ * Dk[ceil(n/2)], Fk[n/2], Gk[(n-1)/2], Rn[n/2], On[n/2-1]; n >= 2. */
+int cgps_decompose_step(const void* Rs, const void* Os, int64_t n, int d, int dtype,
+                        void* Dk, void* Fk, void* Gk, void* Rn, void* On, int* info, void* stream);
+
+/* decompose(Rs, Os) -> packed factor                          cyclic_reduction.py:287-309 */
+int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype,
+                   void* Dp, void* Fp, void* Gp, void* ws, size_t ws_bytes, int* info, void* stream);
+
+/* halfsolve(decomp, y) -> L^-1 T y in CRR layout              cyclic_reduction.py:312-338
+ * mahal_out (optional, device double) receives ||L^-1 T y||^2 = mahal(decomp, y), :461-467. */
+int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+                   const void* y, void* xcrr, void* ws, size_t ws_bytes, double* mahal_out, void* stream);
+
+/* backhalfsolve(decomp, ycrr) -> T^T L^-T ycrr, natural order  cyclic_reduction.py:341-377 */
+int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+                   const void* ycrr, void* x, void* ws, size_t ws_bytes, void* stream);
+
+/* solve(decomp, y) -> J^-1 y                                   cyclic_reduction.py:441-444 */
+int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+               const void* y, void* x, void* ws, size_t ws_bytes, void* stream);
+
+/* det(decomp) -> log|J| = 2 sum log diag(D)                    cyclic_reduction.py:447-458 */
+int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype,
+                       void* ws, size_t ws_bytes, double* out, void* stream);
+
+/* inverse_blocks(decomp) -> diag and lower off-diag blocks of J^-1   cyclic_reduction.py:470-503
+ * Sd[N][d][d], So[N-1][d][d]. */
+int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+                        void* Sd, void* So, void* ws, size_t ws_bytes, void* stream);
+
+/* Measurement hook (bench.py): the next cgps_mahal_logdet call on this host thread
+ * records `start` right before and `stop` right after its dominant kernel (the one
+ * that streams Rs/Os/x from HBM) on the call's stream, then the hook clears itself.
+ * start/stop are hipEvent_t created with timing enabled; nothing synchronises. */
+int cgps_profile_next_call(void* start_event, void* stop_event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGPS_H */

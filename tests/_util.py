@@ -60,8 +60,23 @@ def conditioned_system(n, d, dtype=torch.float64, seed=1234, device="cpu"):
     b = torch.einsum("nij,nj->ni", Rs, x_true)
     b[1:] += torch.einsum("nij,nj->ni", Os, x_true[:-1])
     b[:-1] += torch.einsum("nji,nj->ni", Os, x_true[1:])
-    logdet = 2.0 * float(torch.log(torch.abs(torch.linalg.det(Ld))).sum())
+    logdet = 2.0 * float(_sum_log_abs_det(Ld))
     return Rs.to(dtype), Os.to(dtype), b.to(dtype), x_true.to(dtype), logdet
+
+
+def _sum_log_abs_det(A):
+    """sum_i log|det A_i| by unpivoted elimination vectorised over the batch (the blocks
+    here are 1.5 I + small noise, so no pivoting is needed); plain tensor ops only, so it
+    runs on the GPU without any solver library."""
+    A = A.clone()
+    d = A.shape[-1]
+    total = torch.zeros((), dtype=A.dtype, device=A.device)
+    for j in range(d):
+        piv = A[:, j, j]
+        total = total + torch.log(piv.abs()).sum()
+        if j + 1 < d:
+            A[:, j + 1:, :] -= (A[:, j + 1:, j:j + 1] / piv[:, None, None]) * A[:, j:j + 1, :]
+    return total
 
 
 def bab_blocks(n, alpha, beta, dtype=torch.float64):

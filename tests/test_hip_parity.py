@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  * golden vectors recorded from the unmodified reference,
+  * the CPU oracle on seeded inputs (ragged sizes, every d, both dtypes),
+  * closed-form properties at BASELINE.json's full sizes.
+Tolerances: north_star asks for 1e-5 relative (fp64 log-det / solve) and 1e-4
+(fp32 posterior mean); the fp64 checks here are far tighter (1e-9 .. 1e-11).
+"""
+import numpy as np
+import pytest
+import torch
+
+import _util
+from oracle import cr_oracle as O
+import cyclic_gps.cyclic_reduction as cr
+
+pytestmark = pytest.mark.gpu
+
+CASES = _util.golden_cr_cases()
+IDS = ["d%d_n%d" % (d, n) for d, n, _ in CASES]
+T64 = dict(rtol=1e-9, atol=1e-11)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _catnp(lst, d):
+    return np.concatenate([_np(t).reshape(-1, d, d) for t in lst], axis=0) if lst else np.zeros((0, d, d))
+
+
+@pytest.mark.parametrize("d,n,path", CASES, ids=IDS)
+@pytest.mark.parametrize("where", ["gpu", "cpu"])
+def test_against_reference_golden(d, n, path, where):
+    """Everything the reference computes for this system, recomputed by the HIP path.
+    where="cpu" feeds CPU tensors like the reference's own tests do."""
+    g = np.load(path)
+    dev = "cuda" if where == "gpu" else "cpu"
+    Rs, Os, v = (torch.from_numpy(g[k]).to(dev) for k in ("Rs", "Os", "v"))
+    dec = cr.decompose(Rs, Os)
+    ms, Ds, Fs, Gs = dec
+    assert ms.device.type == "cpu" and ms.dtype == torch.int64
+    assert np.array(ms).tolist() == g["ms"].tolist()
+    assert all(t.device.type == dev for t in Ds)
+    np.testing.assert_allclose(_catnp(Ds, d), g["Dcat"], **T64)
+    np.testing.assert_allclose(_catnp(Fs, d), g["Fcat"].reshape(-1, d, d), **T64)
+    np.testing.assert_allclose(_catnp(Gs, d), g["Gcat"].reshape(-1, d, d), **T64)
+    assert all(float(torch.triu(D, 1).abs().max()) == 0.0 for D in Ds)   # true lower-triangular factors
+    half = cr.halfsolve(dec, v)
+    assert [h.shape[0] for h in half] == [(m + 1) // 2 for m in ms.tolist()]
+    np.testing.assert_allclose(np.concatenate([_np(h) for h in half]), g["half"], **T64)
+    np.testing.assert_allclose(_np(cr.solve(dec, v)), g["solve"], **T64)
+    np.testing.assert_allclose(float(cr.mahal(dec, v)), float(g["mahal"]), rtol=1e-10)
+    np.testing.assert_allclose(float(cr.det(dec)), float(g["det"]), rtol=1e-10, atol=1e-11)
+    for levelwise in (False, True):
+        m, ld = cr._mahal_and_det(Rs, Os, v, levelwise=levelwise)
+        np.testing.assert_allclose([float(m), float(ld)], g["mad"], rtol=1e-10, atol=1e-11)
+    vcrr = _util.split_levels(torch.from_numpy(g["vcrr"]).to(dev), [(m + 1) // 2 for m in ms.tolist()])
+    np.testing.assert_allclose(_np(cr.backhalfsolve(dec, vcrr)), g["back"], **T64)
+    Sd, So = cr.inverse_blocks(dec)
+    np.testing.assert_allclose(_np(Sd), g["Sig_diag"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(_np(So), g["Sig_off"].reshape(-1, d, d), rtol=1e-8, atol=1e-10)
+    if n > 1:
+        (nn, D, F, G), (R1, O1) = cr.decompose_step(Rs, Os)
+        assert nn == n
+        for got, key in ((D, "step_D"), (F, "step_F"), (G, "step_G"), (R1, "step_R"), (O1, "step_O")):
+            np.testing.assert_allclose(_np(got), g[key].reshape(got.shape), **T64)
+
+
+def test_plain_tuple_factor_is_accepted():
+    """A decomp built by someone else (plain tuple of per-level lists, e.g. the oracle's) works too."""
+    g = np.load(CASES[-1][2])
+    Rs, Os, v = (torch.from_numpy(g[k]) for k in ("Rs", "Os", "v"))
+    dec = O.decompose(Rs, Os)
+    np.testing.assert_allclose(_np(cr.solve(dec, v)), g["solve"], **T64)
+    np.testing.assert_allclose(float(cr.det(dec)), float(g["det"]), rtol=1e-10)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_ragged_sizes_against_oracle(d, dtype):
+    """Every N from 1 to 70 plus sizes around the tile widths: even/odd counts at every level."""
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-4)
+    sizes = list(range(1, 71)) + [127, 128, 129, 255, 256, 257, 511, 513, 1000, 1023, 1025, 2049, 4097, 5000]
+    for n in sizes:
+        Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, seed=100 + n)
+        ref_m, ref_ld = O.mahal_and_det(Rs, Os, b)
+        R, Oo, v = Rs.to(dtype).cuda(), Os.to(dtype).cuda(), b.to(dtype).cuda()
+        for levelwise in (False, True):
+            m, ld = cr._mahal_and_det(R, Oo, v, levelwise=levelwise)
+            np.testing.assert_allclose([float(m), float(ld)], [float(ref_m), float(ref_ld)],
+                                       rtol=tol["rtol"], atol=tol["atol"], err_msg="n=%d" % n)
+        dec = cr.decompose(R, Oo)
+        x = cr.solve(dec, v)
+        np.testing.assert_allclose(_np(x).astype(np.float64), _np(x_true), err_msg="n=%d" % n, **tol)
+        np.testing.assert_allclose(float(cr.det(dec)), logdet, rtol=tol["rtol"], atol=tol["atol"])
+        if n in (1, 2, 3, 33, 70, 257, 1000):
+            ref = O.decompose(Rs, Os)
+            for mine, theirs in zip(dec[1:], ref[1:]):
+                for a, bb in zip(mine, theirs):
+                    np.testing.assert_allclose(_np(a).astype(np.float64), _np(bb), err_msg="n=%d" % n, **tol)
+            Sd, So = cr.inverse_blocks(dec)
+            rSd, rSo = O.inverse_blocks(ref)
+            np.testing.assert_allclose(_np(Sd).astype(np.float64), _np(rSd), **tol)
+            np.testing.assert_allclose(_np(So).astype(np.float64), _np(rSo), **tol)
+
+
+def test_known_answers_float32():
+    """The reference's closed-form test (tests/test_cyclic_reduction.py:243-291), float32 like there."""
+    Rs, Os, det_true, inv_true = _util.bab_blocks(10, 5, 2, dtype=torch.float32)
+    x = torch.rand(10, 1, generator=torch.Generator().manual_seed(3))
+    dec = cr.decompose(Rs, Os)
+    assert np.allclose(np.log(det_true), float(cr.det(dec)))
+    m, ld = cr.mahal_and_det(Rs, Os, x=x)
+    assert np.allclose(np.log(det_true), float(ld))
+    assert np.allclose(float(x[:, 0].double() @ torch.from_numpy(inv_true) @ x[:, 0].double()), float(m))
+    Sd, So = cr.inverse_blocks(dec)
+    assert np.allclose(_np(Sd).ravel(), np.diag(inv_true))
+    assert np.allclose(_np(So).ravel(), np.diag(inv_true, -1))
+    Rs, Os, logdet_true, inv_scale = _util.schur_gram_blocks(5, 1.0, 2.0, dtype=torch.float32)
+    dec = cr.decompose(Rs, Os)
+    assert np.allclose(logdet_true, float(cr.det(dec)))
+    m, ld = cr.mahal_and_det(Rs, Os, x=x.reshape(5, 2))
+    assert np.allclose(logdet_true, float(ld))
+    assert np.allclose(inv_scale * float((x * x).sum()), float(m))
+
+
+def test_not_positive_definite_raises():
+    Rs, Os, b, _, _ = _util.conditioned_system(64, 3)
+    Rs[17] = -Rs[17]
+    with pytest.raises(cr.NotPSDError):
+        cr.decompose(Rs.cuda(), Os.cuda())
+    with pytest.raises(cr.NotPSDError):
+        cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
+    Rs[17] = float("nan")
+    with pytest.raises(cr.NotPSDError):
+        cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
+
+
+@pytest.mark.parametrize("N,d,dtype,rtol", [
+    (2 ** 20, 4, torch.float64, 1e-10),     # BASELINE config 2
+    (2 ** 22, 8, torch.float32, 2e-5),      # BASELINE config 3
+    (2 ** 20 + 12345, 4, torch.float64, 1e-10),
+    (2 ** 21 + 1, 5, torch.float64, 1e-10),
+], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64"])
+def test_full_size_closed_form(N, d, dtype, rtol):
+    """Size-independent properties at the benchmark sizes: J = L L^T with L block
+    bidiagonal, so log|J| and the planted solution x_true are known in closed form."""
+    Rs, Os, b, x_true, logdet = _util.conditioned_system(N, d, dtype=dtype, device="cuda")
+    mahal_true = float((x_true.double() * b.double()).sum())
+    for levelwise in (False, True):
+        m, ld = cr._mahal_and_det(Rs, Os, b, levelwise=levelwise)
+        assert abs(float(ld) - logdet) <= rtol * abs(logdet)
+        assert abs(float(m) - mahal_true) <= max(rtol, 1e-9) * 10 * abs(mahal_true)
+    dec = cr.decompose(Rs, Os)
+    x = cr.solve(dec, b)
+    err = float((x.double() - x_true.double()).abs().max())
+    assert err <= (1e-9 if dtype == torch.float64 else 1e-3), err
+    assert abs(float(cr.det(dec)) - logdet) <= rtol * abs(logdet)
+    # the solve is linear: J^-1 (2b) == 2 J^-1 b
+    x2 = cr.solve(dec, 2 * b)
+    assert float((x2 - 2 * x).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-3)
