@@ -316,13 +316,16 @@ int cgps_mahal_logdet(const void* Rs, const void* Os, const void* x, int64_t N, 
   return dispatch(dtype, d, [&](auto t, auto dc) {
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
-    if (!cgps::tile_supported<T, D>())
+    if constexpr (!cgps::tile_supported<T, D>()) {
       return run_levelwise<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, nullptr, nullptr, nullptr, nullptr,
                                  (char*)ws, ws_bytes, out2, info, (hipStream_t)stream);
-    int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, (char*)ws, ws_bytes, out2,
-                                               info, (hipStream_t)stream);
-    if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_mahal_logdet");
-    return check_launch("tile reduction");
+    } else {
+      int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, (char*)ws, ws_bytes,
+                                                 out2, info, (hipStream_t)stream, g_prof_start, g_prof_stop);
+      g_prof_start = g_prof_stop = nullptr;
+      if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_mahal_logdet");
+      return check_launch("tile reduction");
+    }
   });
 }
 
