@@ -1,5 +1,6 @@
 // Fused solve + log-det (mahal_and_det, reference cyclic_reduction.py:380-438):
-// the whole reduction in two or three launches, every input byte read once.
+// the whole reduction in two launches (three and more only for N > 2^20 rows),
+// every input byte read from HBM exactly once.
 //
 // x^T J^-1 x and log|J| do not depend on the elimination order, so this path
 // orders the block Gaussian elimination for the hardware (the factor-emitting
@@ -7,31 +8,38 @@
 //
 //  stage 1, chunk_reduce_kernel: the time axis is cut into chunks of C block
 //    rows, one chunk per lane.  A lane streams its rows from HBM (16-byte loads,
-//    next row prefetched while the current one is eliminated) and eliminates
-//    rows c0 .. c0+C-2 left to right in registers.  The Schur complement of the
-//    chunk interior lands on its two boundary rows: the chunk's own last row
-//    (kept: R_s, y_s, and C_s = its new coupling to the previous chunk's last
-//    row) and that previous row (additive update dRa, dya).  No lane idles and
-//    nothing but the inputs crosses HBM.
+//    the next row is in flight while the current one is eliminated) and
+//    eliminates rows c0 .. c0+C-2 left to right in registers.  The Schur
+//    complement of the chunk interior lands on its two boundary rows: the
+//    chunk's own last row (kept: R_s, y_s and C_s = its new coupling to the
+//    previous chunk's last row) and that previous row (additive update dRa,
+//    dya).  No lane idles and nothing but the inputs crosses HBM.
 //  stage 2, tile_cr: the NT boundary rows of a workgroup form a block
 //    tridiagonal system in LDS that is reduced by even/odd cyclic reduction
-//    (log2 NT levels, one barrier each) to ONE boundary row + the update for
-//    the previous workgroup's boundary row: a "record".
+//    (log2 NT levels, one elimination per lane and one barrier per level) to ONE
+//    boundary row + the update for the previous workgroup's boundary row: a
+//    "record".
 //  stage 3, record_reduce_kernel: records are rows of a (N / (C NT))-row system;
 //    the same tile_cr reduces them (recursively for very large N) and the last
-//    launch eliminates the final row and sums the partial log-det / mahal.
+//    launch eliminates the final row, sums the partial log-det / mahal and
+//    writes the info word.
 //
 // Rows past the end of the system are padded with identity blocks (R = I,
 // O = 0, y = 0): they contribute log 1 = 0 and 0 to the sums, so every tile is
-// full and the reduction code has no ragged cases.
+// full and the reduction code has no ragged cases (levels that would only touch
+// padding are skipped).
 #pragma once
 #include "cgps_level.h"
 
 namespace cgps {
 
-// ---- LDS tile of NT block rows: R[NT][DD], O[NT][DD] (O[i] couples row i and the next
-// active row), y[NT][D].  16-byte granules of a block are XOR-swizzled by a fold of the
-// row index so that the strided row access of every reduction level spreads over banks.
+// ---- LDS tile of NT block rows -------------------------------------------------------
+//   R[NT][DD], y[NT][D]  : the rows; a slot whose row has been eliminated is reused for the
+//                          update that elimination owes its LEFT neighbour (see tile_cr)
+//   Oc[NT+1][DD]         : Oc[i+1] = J[next active row, row i]; Oc[0] = J[first active row,
+//                          row left of the tile]
+// 16-byte granules of a block are XOR-swizzled by a fold of the row index so that the
+// strided row access of every reduction level spreads over the LDS banks.
 template <typename T, int D>
 struct LdsTile {
   static constexpr int DD = D * D;
@@ -39,7 +47,7 @@ struct LdsTile {
   static constexpr int G = (DD % VN == 0) ? DD / VN : 0;          // granules per block
   static constexpr bool SWZ = G >= 2 && (G & (G - 1)) == 0;
   T* R;
-  T* O;
+  T* Oc;
   T* y;
   static __device__ __forceinline__ int key(int row) { return (row ^ (row >> 3) ^ (row >> 6) ^ (row >> 9)) & (G - 1); }
 
@@ -81,11 +89,19 @@ struct LdsTile {
       store_block<T, D>(base + (size_t)row * DD, A);
     }
   }
+  __device__ __forceinline__ void carve(char* smem, int nt) {
+    R = reinterpret_cast<T*>(smem);
+    Oc = R + (size_t)nt * DD;
+    y = Oc + (size_t)(nt + 1) * DD;
+  }
 };
 
+// bytes of the LDS tile + block-reduction scratch + wave-exchange scratch + fail word
 template <typename T, int D>
-__host__ __device__ constexpr size_t tile_lds_bytes(int nt) {
-  return (size_t)nt * (2 * D * D + D) * sizeof(T);
+constexpr size_t stage_lds_bytes(int nt) {
+  size_t tile = ((size_t)nt * (2 * D * D + D) + D * D) * sizeof(T);
+  tile = (tile + 15) & ~(size_t)15;
+  return tile + 2 * (nt / 64) * sizeof(double) + (size_t)(nt / 64) * (D * D + D) * sizeof(T) + 64;
 }
 
 // Running product of pivots with a rare fold into a log sum: one log() per lane
@@ -99,9 +115,45 @@ struct PivotLog {
   __device__ __forceinline__ double value() const { return logsum + log(prod); }
 };
 
-// One elimination: current row (Rc, yc) with coupling Cc to the left boundary row and
-// coupling On to the next row (Rn, yn).  Updates the left boundary accumulators, turns
-// (Rn, yn) into the next current row and Cc into its coupling to the left boundary.
+template <typename T, int D>
+__device__ __forceinline__ void set_identity(T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = (i == j) ? T(1) : T(0);
+}
+template <typename T, int D>
+__device__ __forceinline__ void set_zero(T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = T(0);
+}
+template <typename T, int D>
+__device__ __forceinline__ void set_zero(T (&v)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = T(0);
+}
+// lower(S) = A A^T (fresh)
+template <typename T, int D>
+__device__ __forceinline__ void syrk_lower(T (&S)[D][D], const T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      T s = T(0);
+      if (j <= i) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) s = __builtin_fma(A[i][m], A[j][m], s);
+      }
+      S[i][j] = s;
+    }
+}
+
+// One elimination of the streaming stage: current row (Rc, yc) with coupling Cc to the left
+// boundary row and coupling On to the next row (Rn, yn).  Updates the left boundary
+// accumulators (dRa -= G G^T, dya -= G x), turns (Rn, yn) into the next current row and Cc
+// into its coupling to the left boundary.
 template <typename T, int D>
 __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (&Cc)[D][D], T (&dRa)[D][D],
                                                   T (&dya)[D], T (&On)[D][D], T (&Rn)[D][D], T (&yn)[D],
@@ -127,70 +179,89 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
   }
 }
 
-// Even/odd cyclic reduction of the NT-row system held in the LDS tile, in place, rows
-// at level l living at slots (m+1) 2^l - 1.  Thread k < NT / 2^(l+1) owns the even row
-// e = (2k+1) 2^l - 1 (eliminated) and the odd row o = e + 2^l (kept); the Cholesky of
-// the right even neighbour is recomputed instead of exchanged.  Thread 0 also carries
-// the coupling of the tile's first active row to the row left of the tile
-// (Cleft) and the additive update for that row (dRl, dyl).  On return slot NT-1 holds
-// the tile's boundary row.  (cf. decompose_step, cyclic_reduction.py:225-254.)
+// Even/odd cyclic reduction of the NT-row system in the LDS tile, in place; rows of level l
+// live at slots (m+1) 2^l - 1 (cf. decompose_step, cyclic_reduction.py:225-254).
+// Thread k < NT / 2^(l+1) eliminates the even row e = (2k+1) s - 1, s = 2^l:
+//   D = chol(R_e), x = D^-1 y_e, G = Oc[l]^T D^-T (left neighbour l = e - s, or the row left of
+//   the tile for k = 0), F = Oc[e] D^-T (right neighbour o = e + s);
+//   right neighbour:  R_o -= F F^T, y_o -= F x            (applied now)
+//   left neighbour :  owes G G^T, G x                      (parked in the dead slot e and taken
+//                      off row l = e - s by whoever touches that row at the next level, where
+//                      its parking slot is exactly l + (2s)/2 = e)
+//   new coupling   :  Oc[l] = -F G^T  (J[o, l])
+// so every lane does ONE elimination per level and there is one barrier per level.  Levels
+// whose first active slot is padding (>= n_real) are skipped.  On return slot NT-1 holds the
+// tile's boundary row, Oc[0] its coupling to the row left of the tile and the slots 2^l - 1 of
+// the executed levels what is owed to that row; `levels` = number of executed levels.
 template <typename T, int D, int NT>
-__device__ __forceinline__ void tile_cr(LdsTile<T, D>& t, T (&Cleft)[D][D], T (&dRl)[D][D], T (&dyl)[D],
-                                        PivotLog& pl, double& mah, bool& fail) {
+__device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail) {
   using LT = LdsTile<T, D>;
   const int k = threadIdx.x;
+  int levels = 0;
 #pragma unroll 1
-  for (int s = 1; s < NT; s <<= 1) {
+  for (int s = 1; s < NT && (s - 1) < n_real; s <<= 1, ++levels) {
     if (k < NT / (2 * s)) {
-      const int e = (2 * k + 1) * s - 1, o = e + s, eR = o + s;
+      const int e = (2 * k + 1) * s - 1, o = e + s, h = s >> 1;
       T A[D][D], x[D];
-      Chol<T, D> c;
       LT::load_blk(t.R, e, A);
-      pl.mul(chol_lower<T, D>(A, c, fail));
       load_vec<T, D>(t.y + e * D, x);
+      if (s > 1) {
+        T P[D][D], p[D];
+        LT::load_blk(t.R, e + h, P);
+        load_vec<T, D>(t.y + (e + h) * D, p);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          x[i] -= p[i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) A[i][j] -= P[i][j];
+        }
+      }
+      Chol<T, D> c;
+      pl.mul(chol_lower<T, D>(A, c, fail));
       fwd_subst<T, D>(c, x);
 #pragma unroll
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
-      T F[D][D], Ro[D][D], yo[D];
-      LT::load_blk(t.O, e, F);
+      T Ol[D][D], G[D][D], F[D][D];
+      LT::load_blk(t.Oc, e - s + 1, Ol);
+      rsolve_lt_transposed<T, D>(c, Ol, G);
+      LT::load_blk(t.Oc, e + 1, F);
       rsolve_lt<T, D>(c, F);
+      // right neighbour
+      T Ro[D][D], yo[D];
       LT::load_blk(t.R, o, Ro);
-      syrk_sub_lower<T, D>(Ro, F);
       load_vec<T, D>(t.y + o * D, yo);
-      gemv_sub<T, D>(yo, F, x);
-      if (k == 0) {
-        T G0[D][D];
-        rsolve_lt_transposed<T, D>(c, Cleft, G0);
-        syrk_sub_lower<T, D>(dRl, G0);
-        gemv_sub<T, D>(dyl, G0, x);
-        neg_abt<T, D>(Cleft, F, G0);
-      }
-      if (eR < NT) {
-        bool f2 = false;
-        Chol<T, D> c2;
-        LT::load_blk(t.R, eR, A);
-        chol_lower<T, D>(A, c2, f2);
-        T Oo[D][D], G[D][D], x2[D];
-        LT::load_blk(t.O, o, Oo);
-        rsolve_lt_transposed<T, D>(c2, Oo, G);
-        syrk_sub_lower<T, D>(Ro, G);
-        load_vec<T, D>(t.y + eR * D, x2);
-        fwd_subst<T, D>(c2, x2);
-        gemv_sub<T, D>(yo, G, x2);
-        if (eR + s < NT) {
-          T F2[D][D], On_[D][D];
-          LT::load_blk(t.O, eR, F2);
-          rsolve_lt<T, D>(c2, F2);
-          neg_abt<T, D>(On_, F2, G);
-          LT::store_blk(t.O, o, On_);
+      if (s > 1 && o + h < NT) {
+        T P[D][D], p[D];
+        LT::load_blk(t.R, o + h, P);
+        load_vec<T, D>(t.y + (o + h) * D, p);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          yo[i] -= p[i];
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Ro[i][j] -= P[i][j];
         }
       }
+      syrk_sub_lower<T, D>(Ro, F);
+      gemv_sub<T, D>(yo, F, x);
       mirror_lower<T, D>(Ro);
       LT::store_blk(t.R, o, Ro);
       store_vec<T, D>(t.y + o * D, yo);
+      // what the left neighbour is owed, parked in slot e
+      T W[D][D], wv[D];
+      syrk_lower<T, D>(W, G);
+      set_zero<T, D>(wv);
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int m = 0; m < D; ++m) wv[i] = __builtin_fma(G[i][m], x[m], wv[i]);
+      LT::store_blk(t.R, e, W);
+      store_vec<T, D>(t.y + e * D, wv);
+      neg_abt<T, D>(Ol, F, G);
+      LT::store_blk(t.Oc, e - s + 1, Ol);
     }
     __syncthreads();
   }
+  return levels;
 }
 
 // A record = what a tile leaves behind: its boundary row (Rs, ys), that row's coupling
@@ -203,68 +274,150 @@ struct RecordLayout {
   static constexpr int RS = 0, CS = DD, DRA = 2 * DD, YS = 3 * DD, DYA = 3 * DD + D;
 };
 
+// per-block partial results: {sum x^2, sum log pivots, 1 + first failing row or 0, unused}
+constexpr int PARTIAL_STRIDE = 4;
+
+// Thread 0: add what the executed levels owe the row left of the tile to (dRa, dya) (which
+// already hold the streaming stage's share, as negative sums).
 template <typename T, int D>
-__device__ __forceinline__ void set_identity(T (&A)[D][D]) {
+__device__ __forceinline__ void collect_left_updates(LdsTile<T, D>& t, int levels, T (&dRa)[D][D], T (&dya)[D]) {
+  for (int l = 0; l < levels; ++l) {
+    const int slot = (1 << l) - 1;
+    T P[D][D], p[D];
+    LdsTile<T, D>::load_blk(t.R, slot, P);
+    load_vec<T, D>(t.y + slot * D, p);
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+    for (int i = 0; i < D; ++i) {
+      dya[i] -= p[i];
 #pragma unroll
-    for (int j = 0; j < D; ++j) A[i][j] = (i == j) ? T(1) : T(0);
-}
-template <typename T, int D>
-__device__ __forceinline__ void set_zero(T (&A)[D][D]) {
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) A[i][j] = T(0);
-}
-template <typename T, int D>
-__device__ __forceinline__ void set_zero(T (&v)[D]) {
-#pragma unroll
-  for (int i = 0; i < D; ++i) v[i] = T(0);
+      for (int j = 0; j <= i; ++j) dRa[i][j] -= P[i][j];
+    }
+  }
 }
 
-// Write the tile's record and its partial sums.  Called by all threads after tile_cr.
-template <typename T, int D, int NT>
-__device__ __forceinline__ void emit_record(LdsTile<T, D>& t, const T (&Cleft)[D][D], T (&dRl)[D][D],
-                                            const T (&dyl)[D], T* __restrict__ rec, double mah, double logp,
-                                            double* __restrict__ partial, double* red) {
-  using RL = RecordLayout<T, D>;
+template <int NT>
+__device__ __forceinline__ void write_partial(double mah, double logp, int failrow_plus1, double* __restrict__ partial,
+                                              double* red, int* sfail) {
+  if (failrow_plus1) atomicMin(sfail, failrow_plus1);
+  block_sum2<NT>(mah, logp, red);      // contains a barrier when NT > 64
+  if constexpr (NT <= 64) __syncthreads();
   if (threadIdx.x == 0) {
-    T Rs_[D][D], ys_[D];
-    LdsTile<T, D>::load_blk(t.R, NT - 1, Rs_);
-    load_vec<T, D>(t.y + (NT - 1) * D, ys_);
-    T* r = rec + (size_t)blockIdx.x * RL::STRIDE;
-    store_block<T, D>(r + RL::RS, Rs_);
-    store_block<T, D>(r + RL::CS, Cleft);
-    mirror_lower<T, D>(dRl);
-    store_block<T, D>(r + RL::DRA, dRl);
-    store_vec<T, D>(r + RL::YS, ys_);
-    store_vec<T, D>(r + RL::DYA, dyl);
-  }
-  block_sum2<NT>(mah, logp, red);
-  if (threadIdx.x == 0) {
-    partial[2 * (size_t)blockIdx.x] = mah;
-    partial[2 * (size_t)blockIdx.x + 1] = logp;
+    double* p = partial + PARTIAL_STRIDE * (size_t)blockIdx.x;
+    const int f = *sfail;
+    p[0] = mah;
+    p[1] = logp;
+    p[2] = (f == 0x7fffffff) ? 0.0 : (double)f;
+    p[3] = 0.0;
   }
 }
+
+// The update a lane computed for the row left of its chunk belongs to the previous lane's
+// kept row: fetch it from lane+1 (wave-local shuffle; LDS across the wave boundary) and add it.
+// The tile's last lane keeps its row as is (its update arrives with the next tile's record).
+template <typename T, int D, int NT>
+__device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (&yc)[D], const T (&dRa)[D][D],
+                                                              const T (&dya)[D], T* xch) {
+  constexpr int DD = D * D;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if constexpr (NT > 64) {
+    if (lane == 0 && w > 0) {
+      T* p = xch + (w - 1) * (DD + D);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j2 = 0; j2 <= i; ++j2) p[i * D + j2] = dRa[i][j2];
+        p[DD + i] = dya[i];
+      }
+    }
+    __syncthreads();
+  }
+  T nR[D][D], ny[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j2 = 0; j2 <= i; ++j2) nR[i][j2] = __shfl_down(dRa[i][j2], 1, 64);
+    ny[i] = __shfl_down(dya[i], 1, 64);
+  }
+  if constexpr (NT > 64) {
+    if (lane == 63 && w < NT / 64 - 1) {
+      const T* p = xch + w * (DD + D);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j2 = 0; j2 <= i; ++j2) nR[i][j2] = p[i * D + j2];
+        ny[i] = p[DD + i];
+      }
+    }
+  }
+  if (tid < NT - 1) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j2 = 0; j2 <= i; ++j2) Rc[i][j2] += nR[i][j2];
+      yc[i] += ny[i];
+    }
+  }
+}
+
+// Common second half of both kernels: the lanes' kept rows -> LDS tile -> cyclic reduction ->
+// this tile's record (thread 0).  Returns the number of executed levels.
+template <typename T, int D, int NT>
+__device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D][D], T (&yc)[D], T (&Cc)[D][D],
+                                                     T (&dRa)[D][D], T (&dya)[D], int n_real, T* xch,
+                                                     T* __restrict__ rec_out, PivotLog& pl, double& mah, bool& fail) {
+  using RL = RecordLayout<T, D>;
+  const int tid = threadIdx.x;
+  absorb_right_neighbour_update<T, D, NT>(Rc, yc, dRa, dya, xch);
+  mirror_lower<T, D>(Rc);
+  LdsTile<T, D>::store_blk(t.R, tid, Rc);
+  store_vec<T, D>(t.y + tid * D, yc);
+  LdsTile<T, D>::store_blk(t.Oc, tid, Cc);       // Oc[tid] = J[row tid, row tid-1]; Oc[0]: left of the tile
+  __syncthreads();
+  const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
+  if (rec_out != nullptr && tid == 0) {
+    collect_left_updates<T, D>(t, levels, dRa, dya);
+    T Rs_[D][D], ys_[D], Cs_[D][D];
+    LdsTile<T, D>::load_blk(t.R, NT - 1, Rs_);
+    load_vec<T, D>(t.y + (NT - 1) * D, ys_);
+    LdsTile<T, D>::load_blk(t.Oc, 0, Cs_);
+    T* r = rec_out + (size_t)blockIdx.x * RL::STRIDE;
+    store_block<T, D>(r + RL::RS, Rs_);
+    store_block<T, D>(r + RL::CS, Cs_);
+    mirror_lower<T, D>(dRa);
+    store_block<T, D>(r + RL::DRA, dRa);
+    store_vec<T, D>(r + RL::YS, ys_);
+    store_vec<T, D>(r + RL::DYA, dya);
+  }
+}
+
+template <typename T, int D, int NT>
+struct StageSmem {
+  static constexpr int DD = D * D;
+  LdsTile<T, D> t;
+  double* red;
+  T* xch;
+  int* sfail;
+  __device__ __forceinline__ StageSmem(char* smem) {
+    t.carve(smem, NT);
+    char* tail = smem + ((((size_t)NT * (2 * DD + D) + DD) * sizeof(T) + 15) & ~(size_t)15);
+    red = reinterpret_cast<double*>(tail);
+    xch = reinterpret_cast<T*>(red + 2 * (NT / 64));        // [NT/64][DD + D] wave-boundary exchange
+    sfail = reinterpret_cast<int*>(xch + (NT / 64) * (DD + D));
+  }
+};
 
 // ---- stage 1 -----------------------------------------------------------------------------
 template <typename T, int D, int C, int NT>
 __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
-                                                          T* __restrict__ rec, double* __restrict__ partial,
-                                                          int* __restrict__ info) {
+                                                          T* __restrict__ rec, double* __restrict__ partial) {
   constexpr int DD = D * D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  LdsTile<T, D> t;
-  t.R = reinterpret_cast<T*>(smem);
-  t.O = t.R + NT * DD;
-  t.y = t.O + NT * DD;
-  double* red = reinterpret_cast<double*>(t.y + NT * D);
-  T* xch = reinterpret_cast<T*>(red + 2 * (NT / 64));        // [NT/64][DD + D] wave-boundary exchange
-
+  StageSmem<T, D, NT> sm(smem);
   const int tid = threadIdx.x;
-  const int64_t r0 = ((int64_t)blockIdx.x * NT + tid) * C;
+  if (tid == 0) *sm.sfail = 0x7fffffff;
+  const int64_t lane0 = (int64_t)blockIdx.x * NT;
+  const int64_t r0 = (lane0 + tid) * C;
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
@@ -297,149 +450,115 @@ __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ 
     }
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
-  if (fail) report_fail(info, r0 < N ? r0 : N - 1);
 
-  // the update a lane computed for the row left of its chunk belongs to the previous lane's
-  // kept row: fetch it from lane+1 (wave-local shuffle; LDS across the wave boundary)
-  {
-    const int lane = tid & 63, w = tid >> 6;
-    if (lane == 0 && w > 0) {
-      T* p = xch + (w - 1) * (DD + D);
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-#pragma unroll
-        for (int j2 = 0; j2 <= i; ++j2) p[i * D + j2] = dRa[i][j2];
-        p[DD + i] = dya[i];
-      }
-    }
-    __syncthreads();
-    T nR[D][D], ny[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-#pragma unroll
-      for (int j2 = 0; j2 <= i; ++j2) nR[i][j2] = __shfl_down(dRa[i][j2], 1, 64);
-      ny[i] = __shfl_down(dya[i], 1, 64);
-    }
-    if (lane == 63 && w < NT / 64 - 1) {
-      const T* p = xch + w * (DD + D);
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-#pragma unroll
-        for (int j2 = 0; j2 <= i; ++j2) nR[i][j2] = p[i * D + j2];
-        ny[i] = p[DD + i];
-      }
-    }
-    if (tid < NT - 1) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-#pragma unroll
-        for (int j2 = 0; j2 <= i; ++j2) Rc[i][j2] += nR[i][j2];
-        yc[i] += ny[i];
-      }
-    }
-  }
-  mirror_lower<T, D>(Rc);
-  LdsTile<T, D>::store_blk(t.R, tid, Rc);
-  store_vec<T, D>(t.y + tid * D, yc);
-  if (tid > 0) LdsTile<T, D>::store_blk(t.O, tid - 1, Cc);
-  if (tid != 0) {                       // only thread 0 carries the tile's left boundary
-    set_zero<T, D>(Cc);
-    set_zero<T, D>(dRa);
-    set_zero<T, D>(dya);
-  }
-  __syncthreads();
-  bool fail2 = false;
-  tile_cr<T, D, NT>(t, Cc, dRa, dya, pl, mah, fail2);
-  if (fail2) report_fail(info, r0 < N ? r0 : N - 1);
-  emit_record<T, D, NT>(t, Cc, dRa, dya, rec, mah, pl.value(), partial, red);
+  int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
+  const int n_real = nreal64 > NT ? NT : (int)nreal64;
+  reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec, pl, mah, fail);
+  int64_t frow = r0 < N ? r0 : N - 1;
+  write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial, sm.red, sm.sfail);
 }
 
 // ---- stage 3 -----------------------------------------------------------------------------
-// Records in -> records out (FINAL = false), or -> out2 = {mahal, logdet} (FINAL = true, one
-// workgroup).  Row w of this stage: R = Rs[w] + dRa[w+1], y = ys[w] + dya[w+1], coupling to
-// row w+1: Cs[w+1].
+// Records in -> records out (FINAL = false), or -> out2 = {mahal, logdet} and info (FINAL =
+// true, one workgroup).  Row w of this stage: R = Rs[w] + dRa[w+1], y = ys[w] + dya[w+1],
+// coupling to row w-1: Cs[w].  Each lane first eliminates rc consecutive rows left to right
+// (like stage 1), then the workgroup reduces the NT kept rows.
+template <typename T, int D>
+__device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64_t w, int64_t n, bool add_next,
+                                                T (&R)[D][D], T (&y)[D], T (&Cs)[D][D]) {
+  using RL = RecordLayout<T, D>;
+  if (w < n) {
+    const T* r = rin + (size_t)w * RL::STRIDE;
+    load_block<T, D>(r + RL::RS, R);
+    load_vec<T, D>(r + RL::YS, y);
+    load_block<T, D>(r + RL::CS, Cs);
+    if (add_next && w + 1 < n) {
+      const T* q = rin + (size_t)(w + 1) * RL::STRIDE;
+      T nR[D][D], ny[D];
+      load_block<T, D>(q + RL::DRA, nR);
+      load_vec<T, D>(q + RL::DYA, ny);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) R[i][j] += nR[i][j];
+        y[i] += ny[i];
+      }
+    }
+  } else {
+    set_identity<T, D>(R);
+    set_zero<T, D>(y);
+    set_zero<T, D>(Cs);
+  }
+}
+
 template <typename T, int D, int NT, bool FINAL>
-__global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__ rin, int64_t n,
+__global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__ rin, int64_t n, int rc,
                                                            T* __restrict__ rout, double* __restrict__ partial_out,
                                                            const double* __restrict__ partial_in, int64_t n_partial,
                                                            double* __restrict__ out2, int* __restrict__ info,
                                                            int64_t rows_per_record, int64_t N) {
-  constexpr int DD = D * D;
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  LdsTile<T, D> t;
-  t.R = reinterpret_cast<T*>(smem);
-  t.O = t.R + NT * DD;
-  t.y = t.O + NT * DD;
-  double* red = reinterpret_cast<double*>(t.y + NT * D);
-
+  StageSmem<T, D, NT> sm(smem);
   const int tid = threadIdx.x;
-  const int64_t w = (int64_t)blockIdx.x * NT + tid;
-  T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
-  if (w < n) {
-    const T* r = rin + (size_t)w * RL::STRIDE;
-    load_block<T, D>(r + RL::RS, Rc);
-    load_vec<T, D>(r + RL::YS, yc);
-    load_block<T, D>(r + RL::CS, Cc);
-    load_block<T, D>(r + RL::DRA, dRa);
-    load_vec<T, D>(r + RL::DYA, dya);
-  } else {
-    set_identity<T, D>(Rc);
-    set_zero<T, D>(yc);
-    set_zero<T, D>(Cc);
-    set_zero<T, D>(dRa);
-    set_zero<T, D>(dya);
-  }
-  if (tid < NT - 1 && w + 1 < n) {
-    const T* r = rin + (size_t)(w + 1) * RL::STRIDE;
-    T nR[D][D], ny[D];
-    load_block<T, D>(r + RL::DRA, nR);
-    load_vec<T, D>(r + RL::DYA, ny);
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) Rc[i][j] += nR[i][j];
-      yc[i] += ny[i];
-    }
-  }
-  LdsTile<T, D>::store_blk(t.R, tid, Rc);
-  store_vec<T, D>(t.y + tid * D, yc);
-  if (tid > 0) LdsTile<T, D>::store_blk(t.O, tid - 1, Cc);
-  if (tid != 0) {
-    set_zero<T, D>(Cc);
-    set_zero<T, D>(dRa);
-    set_zero<T, D>(dya);
-  }
-  __syncthreads();
+  if (tid == 0) *sm.sfail = 0x7fffffff;
+  const int64_t w0 = (int64_t)blockIdx.x * NT * rc;       // first record of this tile
+  const int64_t wlast = w0 + (int64_t)NT * rc - 1;        // its last one (kept; update deferred)
+  const int64_t wb = w0 + (int64_t)tid * rc;
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
-  tile_cr<T, D, NT>(t, Cc, dRa, dya, pl, mah, fail);
+  T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
+  set_zero<T, D>(dRa);
+  set_zero<T, D>(dya);
+  load_record_row<T, D>(rin, wb, n, wb != wlast, Rc, yc, Cc);
+  if (tid == 0 && wb < n) {                               // the tile's own share for the row left of it
+    const T* r = rin + (size_t)wb * RL::STRIDE;
+    load_block<T, D>(r + RL::DRA, dRa);
+    load_vec<T, D>(r + RL::DYA, dya);
+  }
+#pragma unroll 1
+  for (int j = 1; j < rc; ++j) {
+    T Rn[D][D], On[D][D], yn[D];
+    load_record_row<T, D>(rin, wb + j, n, wb + j != wlast, Rn, yn, On);
+    eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
+  }
+  const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
+  const int n_real = nthreads_real > NT ? NT : (int)nthreads_real;
+  reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah,
+                                 fail);
+  int64_t frow = (wb + rc) * rows_per_record;
+  frow = (frow < N ? frow : N) - 1;
   if constexpr (!FINAL) {
-    if (fail) {
-      const int64_t last = (w + 1) * rows_per_record;
-      report_fail(info, (last < N ? last : N) - 1);
-    }
-    emit_record<T, D, NT>(t, Cc, dRa, dya, rout, mah, pl.value(), partial_out, red);
+    write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial_out, sm.red, sm.sfail);
   } else {
-    if (tid == 0) {                        // the very last row of the whole system
+    if (tid == 0) {                        // the very last row of the whole system (or padding)
       T A[D][D], x[D];
       Chol<T, D> c;
-      LdsTile<T, D>::load_blk(t.R, NT - 1, A);
+      LdsTile<T, D>::load_blk(sm.t.R, NT - 1, A);
       pl.mul(chol_lower<T, D>(A, c, fail));
-      load_vec<T, D>(t.y + (NT - 1) * D, x);
+      load_vec<T, D>(sm.t.y + (NT - 1) * D, x);
       fwd_subst<T, D>(c, x);
 #pragma unroll
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
     }
-    if (fail) report_fail(info, N - 1);
+    if (fail) atomicMin(sm.sfail, (int)(frow + 1));
     double logp = pl.value();
-    for (int64_t i = tid; i < n_partial; i += NT) {       // partial sums of every earlier launch
-      mah += partial_in[2 * i];
-      logp += partial_in[2 * i + 1];
+    int fmin = 0x7fffffff;
+    for (int64_t i = tid; i < n_partial; i += NT) {       // partial results of every earlier launch
+      const double* p = partial_in + PARTIAL_STRIDE * i;
+      mah += p[0];
+      logp += p[1];
+      if (p[2] != 0.0 && (int)p[2] < fmin) fmin = (int)p[2];
     }
-    block_sum2<NT>(mah, logp, red);
-    if (tid == 0) { out2[0] = mah; out2[1] = logp; }
+    if (fmin != 0x7fffffff) atomicMin(sm.sfail, fmin);
+    block_sum2<NT>(mah, logp, sm.red);
+    if (tid == 0) {
+      out2[0] = mah;
+      out2[1] = logp;
+      const int f = *sm.sfail;
+      *info = (f == 0x7fffffff) ? 0 : f;
+    }
   }
 }
 
@@ -448,21 +567,18 @@ template <typename T, int D> constexpr bool tile_supported() {
   return (sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5);
 }
 template <typename T, int D> struct TileCfg {
-  static constexpr int C = 8;        // rows per lane in stage 1
-  static constexpr int NT1 = 256;    // lanes per workgroup in stage 1
-  static constexpr int NT3 = 256;    // records per workgroup in stage 3
+  static constexpr int C = 16;       // rows per lane in stage 1
+  static constexpr int NT1 = 64;     // lanes per workgroup in stage 1 (one wave: no cross-wave barriers)
+  static constexpr int NT3 = 512;    // lanes per workgroup in stage 3
+  static constexpr int RCMAX = 4;    // records a stage-3 lane eliminates sequentially before the LDS reduction
 };
+constexpr int64_t TILE_ROWS_MIN = 16 * 64;   // smallest rows-per-tile over all TileCfg (workspace sizing)
 
 inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
-  // records of every stage + partial sums; generous closed form (stage 1 has N / (C NT) tiles)
-  const int64_t tiles = N / (8 * 256) + 2;
+  const int64_t tiles = N / TILE_ROWS_MIN + 2;
   const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
-  return ((size_t)(2 * tiles + 4) * stride + (size_t)(2 * tiles + 8) * 16 + 1024 + 255) & ~(size_t)255;
-}
-
-template <typename T, int D>
-size_t stage_lds_bytes(int nt) {
-  return tile_lds_bytes<T, D>(nt) + 2 * (nt / 64) * sizeof(double) + (size_t)(nt / 64) * (D * D + D) * sizeof(T) + 64;
+  const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
+  return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
 }
 
 // returns 0 on success, -1 when the workspace is too small
@@ -474,42 +590,42 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
   const int64_t rows_per_tile = (int64_t)Cfg::C * Cfg::NT1;
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
-  // workspace: [partials: 2*tiles+8 pairs][records A: tiles+2][records B: tiles+2]
+  const int64_t tiles_cap = N / TILE_ROWS_MIN + 2;
   double* partial = reinterpret_cast<double*>(ws);
-  const size_t pbytes = ((size_t)(2 * (N / (8 * 256) + 2) + 8) * 16 + 255) & ~(size_t)255;
+  const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   T* recA = reinterpret_cast<T*>(ws + pbytes);
-  T* recB = recA + (size_t)(tiles + 2) * RL::STRIDE;
-  (void)hipMemsetAsync(info, 0, sizeof(int), st);
+  T* recB = recA + (size_t)(tiles_cap + 2) * RL::STRIDE;
+  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NT3);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds_bytes<T, D>(Cfg::NT1));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds_bytes<T, D>(Cfg::NT3));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds_bytes<T, D>(Cfg::NT3));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
     attr_done = true;
   }
-  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NT3);
   if (ev_start) (void)hipEventRecord(ev_start, st);
-  hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1),
-                     lds1, st, Rs, Os, x, N, recA, partial, info);
+  hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                     Rs, Os, x, N, recA, partial);
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;
   T *rin = recA, *rout = recB;
-  while (n > Cfg::NT3) {
-    const int64_t g = (n + Cfg::NT3 - 1) / Cfg::NT3;
-    hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3),
-                       lds3, st, rin, n, rout, partial + 2 * npart,
-                       (const double*)nullptr, (int64_t)0, (double*)nullptr, info, rows_per_record, N);
+  while (n > (int64_t)Cfg::NT3 * Cfg::RCMAX) {
+    const int64_t per = (int64_t)Cfg::NT3 * Cfg::RCMAX;
+    const int64_t g = (n + per - 1) / per;
+    hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3), lds3, st,
+                       (const T*)rin, n, (int)Cfg::RCMAX, rout, partial + PARTIAL_STRIDE * npart,
+                       (const double*)nullptr, (int64_t)0, (double*)nullptr, (int*)nullptr, rows_per_record, N);
     npart += g;
     n = g;
-    rows_per_record *= Cfg::NT3;
+    rows_per_record *= per;
     T* tmp = rin; rin = rout; rout = tmp;
   }
-  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3),
-                     lds3, st, rin, n, (T*)nullptr, (double*)nullptr,
-                     (const double*)partial, npart, out2, info, rows_per_record, N);
+  const int rc = (int)((n + Cfg::NT3 - 1) / Cfg::NT3);
+  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st, (const T*)rin, n,
+                     rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info, rows_per_record, N);
   return 0;
 }
 

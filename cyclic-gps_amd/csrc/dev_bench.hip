@@ -1,0 +1,265 @@
+// Developer micro-benchmarks for the fused path (not part of the library).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o cyclic-gps_amd/lib/dev_bench cyclic-gps_amd/csrc/dev_bench.hip
+// Run on the GPU box: ./cyclic-gps_amd/lib/dev_bench [log2N]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "cgps_tile.h"
+
+using namespace cgps;
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+// cheap deterministic SPD block-tridiagonal generator: R = (2 + u) I + small symmetric, O small
+template <typename T, int D>
+__global__ void gen_kernel(T* R, T* O, T* y, int64_t N) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  unsigned h = (unsigned)(i * 2654435761u) ^ 0x9e3779b9u;
+  auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (T)((h >> 8) & 0xffff) / (T)65536 - (T)0.5; };
+  for (int a = 0; a < D; ++a)
+    for (int b = 0; b <= a; ++b) {
+      T v = (a == b) ? (T)2.5 + (T)0.2 * rnd() : (T)0.1 * rnd();
+      R[i * D * D + a * D + b] = v;
+      R[i * D * D + b * D + a] = v;
+    }
+  if (i < N - 1)
+    for (int a = 0; a < D * D; ++a) O[i * D * D + a] = (T)0.3 * rnd();
+  for (int a = 0; a < D; ++a) y[i * D + a] = rnd();
+}
+
+// ---- V2: the stage-1 access pattern with no arithmetic to speak of ----------------------
+template <typename T, int D, int C, int NT>
+__global__ __launch_bounds__(NT) void loads_only_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
+                                                        const T* __restrict__ yg, int64_t N, double* out) {
+  constexpr int DD = D * D;
+  const int64_t r0 = ((int64_t)blockIdx.x * NT + threadIdx.x) * C;
+  T acc = 0;
+#pragma unroll 1
+  for (int j = 0; j < C; ++j) {
+    const int64_t rn = r0 + j;
+    if (rn < N - 1) {
+      T Rn[D][D], On[D][D], yn[D];
+      load_block<T, D>(Rg + rn * DD, Rn);
+      load_block<T, D>(Og + rn * DD, On);
+      load_vec<T, D>(yg + rn * D, yn);
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        acc += yn[a];
+#pragma unroll
+        for (int b = 0; b < D; ++b) acc += Rn[a][b] + On[a][b];
+      }
+    }
+  }
+  if (acc == (T)123456.789) out[0] = acc;
+}
+
+// ---- V2b: fully coalesced streaming read of the same bytes ------------------------------
+__global__ __launch_bounds__(256) void coalesced_read_kernel(const double2* __restrict__ p, int64_t n16, double* out) {
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    double2 v = p[i];
+    acc += v.x + v.y;
+  }
+  if (acc == 123456.789) out[0] = acc;
+}
+
+// ---- V1: chunk phase only (no LDS reduction) ---------------------------------------------
+template <typename T, int D, int C, int NT>
+__global__ __launch_bounds__(NT) void chunk_only_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
+                                                        const T* __restrict__ yg, int64_t N, double* out) {
+  constexpr int DD = D * D;
+  const int64_t r0 = ((int64_t)blockIdx.x * NT + threadIdx.x) * C;
+  PivotLog pl;
+  double mah = 0.0;
+  bool fail = false;
+  T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
+  set_zero<T, D>(dRa);
+  set_zero<T, D>(dya);
+  if (r0 < N) {
+    load_block<T, D>(Rg + r0 * DD, Rc);
+    load_vec<T, D>(yg + r0 * D, yc);
+  } else {
+    set_identity<T, D>(Rc);
+    set_zero<T, D>(yc);
+  }
+  if (r0 >= 1 && r0 < N) load_block<T, D>(Og + (r0 - 1) * DD, Cc);
+  else set_zero<T, D>(Cc);
+#pragma unroll 1
+  for (int j = 0; j < C - 1; ++j) {
+    const int64_t rn = r0 + j + 1;
+    T Rn[D][D], On[D][D], yn[D];
+    if (rn < N) {
+      load_block<T, D>(Rg + rn * DD, Rn);
+      load_block<T, D>(Og + (rn - 1) * DD, On);
+      load_vec<T, D>(yg + rn * D, yn);
+    } else {
+      set_identity<T, D>(Rn);
+      set_zero<T, D>(On);
+      set_zero<T, D>(yn);
+    }
+    eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
+  }
+  double s = mah + pl.value() + (double)Rc[0][0] + (double)Cc[0][0] + (double)dRa[0][0] + (double)dya[0] + (double)yc[0];
+  if (s == 123456.789 || fail) out[0] = s;
+}
+
+// ---- V3: LDS reduction only, with per-level clock stamps ----------------------------------
+template <typename T, int D, int NT>
+__global__ __launch_bounds__(NT) void tilecr_only_kernel(double* out, long long* stamps, int reps) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  LdsTile<T, D> t;
+  t.carve(smem, NT);
+  const int tid = threadIdx.x;
+  double mah = 0.0;
+  PivotLog pl;
+  bool fail = false;
+  for (int rep = 0; rep < reps; ++rep) {
+    T Rc[D][D], yc[D], Cc[D][D];
+    set_identity<T, D>(Rc);
+#pragma unroll
+    for (int i = 0; i < D; ++i) { Rc[i][i] = (T)2.5 + (T)0.001 * (T)tid; yc[i] = (T)0.1 * (T)(i + 1); }
+    set_zero<T, D>(Cc);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) Cc[i][j] = (T)0.05 * (T)(i + 1) - (T)0.03 * (T)j;
+    LdsTile<T, D>::store_blk(t.R, tid, Rc);
+    store_vec<T, D>(t.y + tid * D, yc);
+    LdsTile<T, D>::store_blk(t.Oc, tid, Cc);
+    __syncthreads();
+    long long t0 = wall_clock64();
+    tile_cr<T, D, NT>(t, NT, pl, mah, fail);
+    long long t1 = wall_clock64();
+    if (tid == 0 && blockIdx.x == 0) stamps[rep] = t1 - t0;
+    __syncthreads();
+  }
+  double s = mah + pl.value();
+  if (s == 123456.789 || fail) out[0] = s;
+}
+
+
+// ---- probe: lane maps of v_mfma_f64_4x4x4_4b_f64 ------------------------------------------
+__global__ void mfma_probe_kernel(int* table) {
+  const int lane = threadIdx.x;
+  for (int la = 0; la < 64; ++la)
+    for (int lb = 0; lb < 64; ++lb) {
+      double a = (lane == la) ? 1.0 : 0.0, b = (lane == lb) ? 1.0 : 0.0;
+      double d = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
+      if (d != 0.0) table[la * 64 + lb] = lane;
+    }
+}
+static void run_mfma_probe() {
+  int* table;
+  CK(hipMalloc(&table, 4096 * sizeof(int)));
+  CK(hipMemset(table, 0xff, 4096 * sizeof(int)));
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, table);
+  CK(hipDeviceSynchronize());
+  std::vector<int> h(4096);
+  CK(hipMemcpy(h.data(), table, 4096 * sizeof(int), hipMemcpyDeviceToHost));
+  printf("mfma_f64_4x4x4 probe: for A-lane la: list of (B-lane -> D-lane)\n");
+  for (int la = 0; la < 64; ++la) {
+    if (!(la < 20 || la == 32 || la == 48)) continue;
+    printf("  la=%2d:", la);
+    for (int lb = 0; lb < 64; ++lb)
+      if (h[la * 64 + lb] >= 0) printf(" (%d->%d)", lb, h[la * 64 + lb]);
+    printf("\n");
+  }
+}
+
+template <typename F>
+float time_ms(F&& launch, int reps, hipStream_t st) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  launch();
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(a, st));
+  for (int i = 0; i < reps; ++i) launch();
+  CK(hipEventRecord(b, st));
+  CK(hipEventSynchronize(b));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, a, b));
+  CK(hipGetLastError());
+  return ms / reps;
+}
+
+template <typename T, int D, int C, int NT>
+void run_chunk_variants(const T* R, const T* O, const T* y, int64_t N, double* out, hipStream_t st, double bytes) {
+  const int64_t tiles = (N + (int64_t)C * NT - 1) / ((int64_t)C * NT);
+  float a = time_ms([&] { hipLaunchKernelGGL((loads_only_kernel<T, D, C, NT>), dim3((unsigned)tiles), dim3(NT), 0, st, R, O, y, N, out); }, 20, st);
+  float b = time_ms([&] { hipLaunchKernelGGL((chunk_only_kernel<T, D, C, NT>), dim3((unsigned)tiles), dim3(NT), 0, st, R, O, y, N, out); }, 20, st);
+  printf("C=%2d NT=%3d tiles=%6lld : loads-only %7.2f us (%5.2f TB/s)   chunk-only %7.2f us (%5.2f TB/s)\n", C, NT,
+         (long long)tiles, a * 1e3, bytes / (a * 1e-3) / 1e12, b * 1e3, bytes / (b * 1e-3) / 1e12);
+}
+
+int main(int argc, char** argv) {
+  using T = double;
+  constexpr int D = 4;
+  const int lg = argc > 1 ? atoi(argv[1]) : 20;
+  const int64_t N = (int64_t)1 << lg;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  T *R, *O, *y;
+  double* out;
+  CK(hipMalloc(&R, N * D * D * sizeof(T)));
+  CK(hipMalloc(&O, N * D * D * sizeof(T)));
+  CK(hipMalloc(&y, N * D * sizeof(T)));
+  CK(hipMalloc(&out, 4096));
+  hipLaunchKernelGGL((gen_kernel<T, D>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, R, O, y, N);
+  CK(hipStreamSynchronize(st));
+  const double bytes = ((2.0 * N - 1) * D * D + N * D) * sizeof(T);
+  printf("N=2^%d d=%d fp64  algorithmic bytes %.1f MB\n", lg, D, bytes / 1e6);
+  run_mfma_probe();
+
+  {  // coalesced streaming read of R and O back to back (ceiling for read-only streaming)
+    const int64_t n16 = N * D * D * sizeof(T) / 16;
+    float ms = time_ms([&] {
+      hipLaunchKernelGGL(coalesced_read_kernel, dim3(2048), dim3(256), 0, st, (const double2*)R, n16, out);
+      hipLaunchKernelGGL(coalesced_read_kernel, dim3(2048), dim3(256), 0, st, (const double2*)O, n16, out);
+    }, 20, st);
+    printf("coalesced read of R+O (2 launches): %7.2f us  (%5.2f TB/s)\n", ms * 1e3, 2.0 * n16 * 16 / (ms * 1e-3) / 1e12);
+  }
+  run_chunk_variants<T, D, 4, 256>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 8, 256>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 16, 256>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 8, 128>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 8, 64>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 16, 64>(R, O, y, N, out, st, bytes);
+  run_chunk_variants<T, D, 32, 64>(R, O, y, N, out, st, bytes);
+
+  {  // LDS reduction only
+    long long* stamps;
+    CK(hipMalloc(&stamps, 64 * sizeof(long long)));
+    auto run = [&](auto ntc, int grid) {
+      constexpr int NT = decltype(ntc)::value;
+      const size_t lds = stage_lds_bytes<T, D>(NT);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tilecr_only_kernel<T, D, NT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      float ms = time_ms([&] { hipLaunchKernelGGL((tilecr_only_kernel<T, D, NT>), dim3(grid), dim3(NT), lds, st, out, stamps, 4); }, 10, st);
+      long long h[4];
+      CK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
+      int levels = 0;
+      for (int s = 1; s < NT; s <<= 1) ++levels;
+      printf("tile_cr NT=%3d grid=%4d: kernel %7.2f us for 4 reps; in-kernel per rep (100MHz ticks -> us): %.2f %.2f %.2f %.2f  (%d levels => %.2f us/level)\n",
+             NT, grid, ms * 1e3, h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0, levels, h[3] / 100.0 / levels);
+    };
+    run(std::integral_constant<int, 256>{}, 1);
+    run(std::integral_constant<int, 256>{}, 512);
+    run(std::integral_constant<int, 512>{}, 1);
+    run(std::integral_constant<int, 64>{}, 1);
+  }
+  return 0;
+}
