@@ -104,7 +104,7 @@ def main():
         Rs, Os, b, x_true, logdet_true = make_system(rows, d, dtype, dev)
         mahal_true = float((x_true.double() * b.double()).sum())
     else:
-        Rs, Os, b, mahal_true, logdet_true = sharded.make_sharded_system(n_total, d, dtype, dev, rank, world)
+        Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(n_total, d, dtype, dev, rank, world)
     out = torch.zeros(2, dtype=torch.float64, device=dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     ws, ws_bytes = _hip.workspace(rows + 1, d, dtype, _hip.OP_MAHAL_LOGDET, dev)
@@ -118,7 +118,8 @@ def main():
             _hip.check(fn(_hip.ptr(Rs), _hip.ptr(Os), _hip.ptr(b), rows, d, dcode, _hip.ptr(ws), ws_bytes,
                           _hip.ptr(out), _hip.ptr(info), sp))
     else:
-        plan = sharded.ShardedMahalLogdet(Rs, Os, b, n_total, d, rank, world)
+        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world)
+        info = plan.ops.info
 
         def step():
             plan.run(out)

@@ -24,10 +24,9 @@
 //    launch eliminates the final row, sums the partial log-det / mahal and
 //    writes the info word.
 //
-// Rows past the end of the system are padded with identity blocks (R = I,
-// O = 0, y = 0): they contribute log 1 = 0 and 0 to the sums, so every tile is
-// full and the reduction code has no ragged cases (levels that would only touch
-// padding are skipped).
+// Ragged sizes are exact, no padding rows: a short chunk / tile simply keeps its
+// last REAL row, which is what lets a shard of a larger system (one per GPU) be
+// reduced by the same code to a single record the next shard couples to.
 #pragma once
 #include "cgps_level.h"
 
@@ -189,23 +188,31 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 //                      off row l = e - s by whoever touches that row at the next level, where
 //                      its parking slot is exactly l + (2s)/2 = e)
 //   new coupling   :  Oc[l] = -F G^T  (J[o, l])
-// so every lane does ONE elimination per level and there is one barrier per level.  Levels
-// whose first active slot is padding (>= n_real) are skipped.  On return slot NT-1 holds the
-// tile's boundary row, Oc[0] its coupling to the row left of the tile and the slots 2^l - 1 of
-// the executed levels what is owed to that row; `levels` = number of executed levels.
+// so every lane does ONE elimination per level and there is one barrier per level.
+// Ragged tiles (n_real <= NT rows) are exact: the tile's LAST real row K = n_real - 1 is never
+// eliminated (it is the boundary the next tile / shard couples to), which is the reference's
+// odd/even size rule (cyclic_reduction.py:240-248, 262-280) with the last row always kept: at
+// a level with M = (K+1)/s regular rows, thread k eliminates regular row 2k unless it is K, and
+// its right neighbour is regular row 2k+1, or K when 2k is the last regular row.
+// On return slot K holds the tile's boundary row, Oc[0] its coupling to the row left of the
+// tile and the slots 2^l - 1 of the executed levels what is owed to that row; returns the
+// number of executed levels.
 template <typename T, int D, int NT>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail) {
   using LT = LdsTile<T, D>;
   const int k = threadIdx.x;
+  const int K = n_real - 1;
   int levels = 0;
 #pragma unroll 1
-  for (int s = 1; s < NT && (s - 1) < n_real; s <<= 1, ++levels) {
-    if (k < NT / (2 * s)) {
-      const int e = (2 * k + 1) * s - 1, o = e + s, h = s >> 1;
+  for (int s = 1; (s - 1) < K; s <<= 1, ++levels) {
+    const int M = (K + 1) / s;
+    const int e = (2 * k + 1) * s - 1;
+    if (2 * k < M && e != K) {
+      const int o = (2 * k + 1 < M) ? e + s : K, h = s >> 1;
       T A[D][D], x[D];
       LT::load_blk(t.R, e, A);
       load_vec<T, D>(t.y + e * D, x);
-      if (s > 1) {
+      if (s > 1 && e + h < K) {
         T P[D][D], p[D];
         LT::load_blk(t.R, e + h, P);
         load_vec<T, D>(t.y + (e + h) * D, p);
@@ -230,7 +237,7 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
       T Ro[D][D], yo[D];
       LT::load_blk(t.R, o, Ro);
       load_vec<T, D>(t.y + o * D, yo);
-      if (s > 1 && o + h < NT) {
+      if (s > 1 && o + h < K) {
         T P[D][D], p[D];
         LT::load_blk(t.R, o + h, P);
         load_vec<T, D>(t.y + (o + h) * D, p);
@@ -316,7 +323,7 @@ __device__ __forceinline__ void write_partial(double mah, double logp, int failr
 // The tile's last lane keeps its row as is (its update arrives with the next tile's record).
 template <typename T, int D, int NT>
 __device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (&yc)[D], const T (&dRa)[D][D],
-                                                              const T (&dya)[D], T* xch) {
+                                                              const T (&dya)[D], T* xch, int n_real) {
   constexpr int DD = D * D;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if constexpr (NT > 64) {
@@ -349,7 +356,7 @@ __device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (
       }
     }
   }
-  if (tid < NT - 1) {
+  if (tid < n_real - 1) {
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
@@ -367,18 +374,21 @@ __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D
                                                      T* __restrict__ rec_out, PivotLog& pl, double& mah, bool& fail) {
   using RL = RecordLayout<T, D>;
   const int tid = threadIdx.x;
-  absorb_right_neighbour_update<T, D, NT>(Rc, yc, dRa, dya, xch);
-  mirror_lower<T, D>(Rc);
-  LdsTile<T, D>::store_blk(t.R, tid, Rc);
-  store_vec<T, D>(t.y + tid * D, yc);
-  LdsTile<T, D>::store_blk(t.Oc, tid, Cc);       // Oc[tid] = J[row tid, row tid-1]; Oc[0]: left of the tile
+  // lanes past the tile's real rows carry nothing (zero updates, never stored or read)
+  absorb_right_neighbour_update<T, D, NT>(Rc, yc, dRa, dya, xch, n_real);
+  if (tid < n_real) {
+    mirror_lower<T, D>(Rc);
+    LdsTile<T, D>::store_blk(t.R, tid, Rc);
+    store_vec<T, D>(t.y + tid * D, yc);
+    LdsTile<T, D>::store_blk(t.Oc, tid, Cc);     // Oc[tid] = J[row tid, row tid-1]; Oc[0]: left of the tile
+  }
   __syncthreads();
   const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
   if (rec_out != nullptr && tid == 0) {
     collect_left_updates<T, D>(t, levels, dRa, dya);
     T Rs_[D][D], ys_[D], Cs_[D][D];
-    LdsTile<T, D>::load_blk(t.R, NT - 1, Rs_);
-    load_vec<T, D>(t.y + (NT - 1) * D, ys_);
+    LdsTile<T, D>::load_blk(t.R, n_real - 1, Rs_);
+    load_vec<T, D>(t.y + (n_real - 1) * D, ys_);
     LdsTile<T, D>::load_blk(t.Oc, 0, Cs_);
     T* r = rec_out + (size_t)blockIdx.x * RL::STRIDE;
     store_block<T, D>(r + RL::RS, Rs_);
@@ -410,7 +420,10 @@ struct StageSmem {
 template <typename T, int D, int C, int NT>
 __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
+                                                          const T* __restrict__ Oleft,
                                                           T* __restrict__ rec, double* __restrict__ partial) {
+  // Oleft: J[row 0 of this shard, last row of the previous shard], or nullptr when row 0 is the
+  // first row of the whole system.
   constexpr int DD = D * D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   StageSmem<T, D, NT> sm(smem);
@@ -425,29 +438,24 @@ __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ 
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
   set_zero<T, D>(dya);
+  // a lane past the end of the shard holds nothing; a short last chunk keeps its last real row
+  set_zero<T, D>(Rc);
+  set_zero<T, D>(yc);
+  set_zero<T, D>(Cc);
   if (r0 < N) {
     load_block<T, D>(Rg + r0 * DD, Rc);
     load_vec<T, D>(yg + r0 * D, yc);
-  } else {
-    set_identity<T, D>(Rc);
-    set_zero<T, D>(yc);
+    if (r0 >= 1) load_block<T, D>(Og + (r0 - 1) * DD, Cc);
+    else if (Oleft != nullptr) load_block<T, D>(Oleft, Cc);
   }
-  if (r0 >= 1 && r0 < N) load_block<T, D>(Og + (r0 - 1) * DD, Cc);
-  else set_zero<T, D>(Cc);
-
 #pragma unroll 1
   for (int j = 0; j < C - 1; ++j) {
     const int64_t rn = r0 + j + 1;
+    if (rn >= N) break;
     T Rn[D][D], On[D][D], yn[D];
-    if (rn < N) {
-      load_block<T, D>(Rg + rn * DD, Rn);
-      load_block<T, D>(Og + (rn - 1) * DD, On);
-      load_vec<T, D>(yg + rn * D, yn);
-    } else {
-      set_identity<T, D>(Rn);
-      set_zero<T, D>(On);
-      set_zero<T, D>(yn);
-    }
+    load_block<T, D>(Rg + rn * DD, Rn);
+    load_block<T, D>(Og + (rn - 1) * DD, On);
+    load_vec<T, D>(yg + rn * D, yn);
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
 
@@ -464,16 +472,17 @@ __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ 
 // coupling to row w-1: Cs[w].  Each lane first eliminates rc consecutive rows left to right
 // (like stage 1), then the workgroup reduces the NT kept rows.
 template <typename T, int D>
-__device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64_t w, int64_t n, bool add_next,
+__device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64_t rstride, int64_t w, int64_t n,
+                                                bool add_next,
                                                 T (&R)[D][D], T (&y)[D], T (&Cs)[D][D]) {
   using RL = RecordLayout<T, D>;
   if (w < n) {
-    const T* r = rin + (size_t)w * RL::STRIDE;
+    const T* r = rin + (size_t)w * rstride;
     load_block<T, D>(r + RL::RS, R);
     load_vec<T, D>(r + RL::YS, y);
     load_block<T, D>(r + RL::CS, Cs);
     if (add_next && w + 1 < n) {
-      const T* q = rin + (size_t)(w + 1) * RL::STRIDE;
+      const T* q = rin + (size_t)(w + 1) * rstride;
       T nR[D][D], ny[D];
       load_block<T, D>(q + RL::DRA, nR);
       load_vec<T, D>(q + RL::DYA, ny);
@@ -484,8 +493,8 @@ __device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64
         y[i] += ny[i];
       }
     }
-  } else {
-    set_identity<T, D>(R);
+  } else {                      // a lane past the last record holds nothing
+    set_zero<T, D>(R);
     set_zero<T, D>(y);
     set_zero<T, D>(Cs);
   }
@@ -496,14 +505,17 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
                                                            T* __restrict__ rout, double* __restrict__ partial_out,
                                                            const double* __restrict__ partial_in, int64_t n_partial,
                                                            double* __restrict__ out2, int* __restrict__ info,
-                                                           int64_t rows_per_record, int64_t N) {
+                                                           int64_t rows_per_record, int64_t N, int64_t rstride,
+                                                           int64_t pstride) {
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   StageSmem<T, D, NT> sm(smem);
   const int tid = threadIdx.x;
   if (tid == 0) *sm.sfail = 0x7fffffff;
   const int64_t w0 = (int64_t)blockIdx.x * NT * rc;       // first record of this tile
-  const int64_t wlast = w0 + (int64_t)NT * rc - 1;        // its last one (kept; update deferred)
+  int64_t wend = w0 + (int64_t)NT * rc;
+  if (wend > n) wend = n;
+  const int64_t wlast = wend - 1;                         // its last one (kept; its update is deferred)
   const int64_t wb = w0 + (int64_t)tid * rc;
   PivotLog pl;
   double mah = 0.0;
@@ -511,16 +523,17 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
   set_zero<T, D>(dya);
-  load_record_row<T, D>(rin, wb, n, wb != wlast, Rc, yc, Cc);
+  load_record_row<T, D>(rin, rstride, wb, n, wb != wlast, Rc, yc, Cc);
   if (tid == 0 && wb < n) {                               // the tile's own share for the row left of it
-    const T* r = rin + (size_t)wb * RL::STRIDE;
+    const T* r = rin + (size_t)wb * rstride;
     load_block<T, D>(r + RL::DRA, dRa);
     load_vec<T, D>(r + RL::DYA, dya);
   }
 #pragma unroll 1
   for (int j = 1; j < rc; ++j) {
+    if (wb + j >= n) break;
     T Rn[D][D], On[D][D], yn[D];
-    load_record_row<T, D>(rin, wb + j, n, wb + j != wlast, Rn, yn, On);
+    load_record_row<T, D>(rin, rstride, wb + j, n, wb + j != wlast, Rn, yn, On);
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
   const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
@@ -532,12 +545,12 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   if constexpr (!FINAL) {
     write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial_out, sm.red, sm.sfail);
   } else {
-    if (tid == 0) {                        // the very last row of the whole system (or padding)
+    if (tid == 0) {                        // the very last row of the whole system
       T A[D][D], x[D];
       Chol<T, D> c;
-      LdsTile<T, D>::load_blk(sm.t.R, NT - 1, A);
+      LdsTile<T, D>::load_blk(sm.t.R, n_real - 1, A);
       pl.mul(chol_lower<T, D>(A, c, fail));
-      load_vec<T, D>(sm.t.y + (NT - 1) * D, x);
+      load_vec<T, D>(sm.t.y + (n_real - 1) * D, x);
       fwd_subst<T, D>(c, x);
 #pragma unroll
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
@@ -546,7 +559,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
     double logp = pl.value();
     int fmin = 0x7fffffff;
     for (int64_t i = tid; i < n_partial; i += NT) {       // partial results of every earlier launch
-      const double* p = partial_in + PARTIAL_STRIDE * i;
+      const double* p = partial_in + pstride * i;
       mah += p[0];
       logp += p[1];
       if (p[2] != 0.0 && (int)p[2] < fmin) fmin = (int)p[2];
@@ -581,10 +594,38 @@ inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
   return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
 }
 
+// {sum, sum, smallest non-zero, 0} over per-block partial results
+__global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __restrict__ partial, int64_t count,
+                                                            double* __restrict__ out4) {
+  __shared__ double red[2 * 4];
+  __shared__ int sf;
+  if (threadIdx.x == 0) sf = 0x7fffffff;
+  __syncthreads();
+  double a = 0.0, b = 0.0;
+  for (int64_t i = threadIdx.x; i < count; i += 256) {
+    const double* p = partial + PARTIAL_STRIDE * i;
+    a += p[0];
+    b += p[1];
+    if (p[2] != 0.0) atomicMin(&sf, (int)p[2]);
+  }
+  block_sum2<256>(a, b, red);
+  if (threadIdx.x == 0) {
+    out4[0] = a;
+    out4[1] = b;
+    out4[2] = (sf == 0x7fffffff) ? 0.0 : (double)sf;
+    out4[3] = 0.0;
+  }
+}
+
+// The fused pipeline.  Whole system: shard_record == nullptr, results in out2 / info.
+// One shard of a sharded system: shard_record / shard_partial receive the shard's single record
+// and its {mahal, logdet, fail, 0} partial; Oleft = J[first row of the shard, last row of the
+// previous shard] (nullptr for the first shard).
 // returns 0 on success, -1 when the workspace is too small
 template <typename T, int D>
 int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char* ws, size_t ws_bytes, double* out2,
-                          int* info, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+                          int* info, hipStream_t st, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr,
+                          const T* Oleft = nullptr, T* shard_record = nullptr, double* shard_partial = nullptr) {
   using Cfg = TileCfg<T, D>;
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
@@ -608,24 +649,57 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   }
   if (ev_start) (void)hipEventRecord(ev_start, st);
   hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                     Rs, Os, x, N, recA, partial);
+                     Rs, Os, x, N, Oleft, recA, partial);
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;
   T *rin = recA, *rout = recB;
-  while (n > (int64_t)Cfg::NT3 * Cfg::RCMAX) {
-    const int64_t per = (int64_t)Cfg::NT3 * Cfg::RCMAX;
+  // a shard is reduced all the way to ONE record; the whole system stops as soon as the final
+  // workgroup can take what is left
+  while (shard_record ? n > 1 : n > (int64_t)Cfg::NT3 * Cfg::RCMAX) {
+    int rc = (int)((n + Cfg::NT3 - 1) / Cfg::NT3);
+    if (rc > Cfg::RCMAX) rc = Cfg::RCMAX;
+    const int64_t per = (int64_t)Cfg::NT3 * rc;
     const int64_t g = (n + per - 1) / per;
     hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3), lds3, st,
-                       (const T*)rin, n, (int)Cfg::RCMAX, rout, partial + PARTIAL_STRIDE * npart,
-                       (const double*)nullptr, (int64_t)0, (double*)nullptr, (int*)nullptr, rows_per_record, N);
+                       (const T*)rin, n, rc, rout, partial + PARTIAL_STRIDE * npart, (const double*)nullptr,
+                       (int64_t)0, (double*)nullptr, (int*)nullptr, rows_per_record, N, (int64_t)RL::STRIDE,
+                       (int64_t)PARTIAL_STRIDE);
     npart += g;
     n = g;
     rows_per_record *= per;
     T* tmp = rin; rin = rout; rout = tmp;
   }
+  if (shard_record) {
+    (void)hipMemcpyAsync(shard_record, rin, RL::STRIDE * sizeof(T), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(sum_partials4_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, npart, shard_partial);
+    return 0;
+  }
   const int rc = (int)((n + Cfg::NT3 - 1) / Cfg::NT3);
   hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st, (const T*)rin, n,
-                     rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info, rows_per_record, N);
+                     rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info, rows_per_record, N,
+                     (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+  return 0;
+}
+
+// Finish a sharded reduction: P shard records (in shard order) + their partial results ->
+// out2 = {mahal, logdet}, info.  One workgroup; P <= NT3 * RCMAX.  rstride / pstride: distance
+// between consecutive records (elements of T) / partials (doubles), so both can be read in place
+// from an all-gather receive buffer of [record | partial] messages.
+template <typename T, int D>
+int run_tile_finish(const T* records, int64_t rstride, const double* partials, int64_t pstride, int64_t P,
+                    int64_t rows_per_shard, int64_t N, double* out2, int* info, hipStream_t st) {
+  using Cfg = TileCfg<T, D>;
+  if (P < 1 || P > (int64_t)Cfg::NT3 * Cfg::RCMAX) return -1;
+  const size_t lds3 = stage_lds_bytes<T, D>(Cfg::NT3);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    attr_done = true;
+  }
+  const int rc = (int)((P + Cfg::NT3 - 1) / Cfg::NT3);
+  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st, records, P, rc,
+                     (T*)nullptr, (double*)nullptr, partials, P, out2, info, rows_per_shard, N, rstride, pstride);
   return 0;
 }
 

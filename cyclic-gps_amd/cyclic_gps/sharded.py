@@ -1,0 +1,157 @@
+"""Time-axis sharding of the fused solve + log-det over the GPUs of one node.
+
+The reference is single-process; this is the multi-GPU form BASELINE.json asks for
+(one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI).
+
+Rank g owns a contiguous run of block rows.  Because block Gaussian elimination of
+the shard interior only touches the shard's two boundary rows (its own last row,
+and the last row of the previous shard), every rank reduces its shard with NO
+communication to a single *record* (cgps_shard_reduce: last row, its coupling to
+the previous shard's last row, the additive update for that row) plus partial
+sums.  ONE all-gather of world_size messages (a few hundred bytes each) then gives
+every rank the world_size-row boundary system, which cgps_finish_records reduces
+redundantly on every rank.  That is the per-level halo exchange of boundary blocks
+collapsed into a single exchange: the halo payload of all levels is the record.
+
+run() enqueues exactly: shard kernels -> all_gather_into_tensor -> finish kernel.
+The library writes its record and partial sums straight into the send buffer and
+reads the gathered messages in place, so there is no packing / unpacking work.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+
+def shard_bounds(n_total, world, rank):
+    """[lo, hi) of rank's rows: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def record_elems(d, dtype):
+    n = ctypes.c_int64(0)
+    _hip.check(_hip.lib().cgps_record_elems(d, _hip.dtype_code(dtype), ctypes.byref(n)))
+    return n.value
+
+
+def message_layout(d, dtype):
+    """(record bytes, message bytes): a message is [record | 4 float64 partial results]."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    rec = record_elems(d, dtype) * esz
+    return rec, rec + 32
+
+
+class HipShardOps:
+    """The two device steps, through the C ABI (include/cgps.h)."""
+
+    def __init__(self, n_loc, d, dtype, device):
+        self.n_loc, self.d, self.dtype = n_loc, d, dtype
+        self.ws, self.ws_bytes = _hip.workspace(n_loc, d, dtype, _hip.OP_MAHAL_LOGDET, device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def shard_reduce(self, Rs, Os, x, O_left, send, rec_bytes):
+        base = send.data_ptr()
+        _hip.check(_hip.lib().cgps_shard_reduce(
+            _hip.ptr(Rs), _hip.ptr(Os), _hip.ptr(x), _hip.ptr(O_left), self.n_loc, self.d,
+            _hip.dtype_code(self.dtype), _hip.ptr(self.ws), self.ws_bytes, ctypes.c_void_p(base),
+            ctypes.c_void_p(base + rec_bytes), _hip.stream_ptr()))
+
+    def finish(self, recv, world, rec_bytes, msg_bytes, rows_per_shard, n_total, out):
+        base = recv.data_ptr()
+        _hip.check(_hip.lib().cgps_finish_records(
+            ctypes.c_void_p(base), msg_bytes, ctypes.c_void_p(base + rec_bytes), msg_bytes, world,
+            rows_per_shard, n_total, self.d, _hip.dtype_code(self.dtype), _hip.ptr(out), _hip.ptr(self.info),
+            _hip.stream_ptr()))
+
+
+class ShardedMahalLogdet:
+    """mahal_and_det of ONE block-tridiagonal system split over the ranks of `group`.
+
+    Rs [n_loc,d,d], Os [n_loc-1,d,d] (couplings inside the shard), x [n_loc,d] are this rank's
+    rows; O_left [d,d] = J[first local row, last row of the previous rank] (None on rank 0).
+    run() returns a 2-element float64 tensor {x^T J^-1 x, log|J|}, identical on every rank.
+    `ops` is the pair of device steps (default: the HIP library); tests inject a dense-algebra
+    stand-in to exercise the collective plumbing on CPU/gloo."""
+
+    def __init__(self, Rs, Os, x, O_left, n_total, rank, world, group=None, ops=None):
+        self.Rs, self.Os, self.x, self.O_left = Rs, Os, x, O_left
+        self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
+        self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
+        self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
+        self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
+        dev = Rs.device
+        self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(world * self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.out = torch.empty(2, dtype=torch.float64, device=dev)
+
+    def run(self, out=None):
+        out = self.out if out is None else out
+        self.ops.shard_reduce(self.Rs, self.Os, self.x, self.O_left, self.send, self.rec_bytes)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)      # the ONE collective
+            src = self.recv
+        else:
+            src = self.send
+        self.ops.finish(src, self.world, self.rec_bytes, self.msg_bytes, self.n_loc, self.n_total, out)
+        return out
+
+
+def make_sharded_system(n_total, d, dtype, device, rank, world, group=None, seed=1234):
+    """This rank's shard of the conditioned bidiagonal-factor system of SURVEY.md 8(d)
+    (J = L L^T, L block lower bidiagonal: closed-form log-det and planted solution), generated
+    with NO global tensor: ranks only exchange their boundary blocks of L and x_true.
+    Returns Rs, Os, b, O_left, mahal_true, logdet_true (the last two global python floats)."""
+    lo, hi = shard_bounds(n_total, world, rank)
+    n = hi - lo
+    g = torch.Generator(device=device).manual_seed(seed + 7919 * rank)
+    kw = dict(dtype=torch.float64, device=device, generator=g)
+    Ld = 1.5 * torch.eye(d, dtype=torch.float64, device=device) + 0.1 * torch.randn(n, d, d, **kw)
+    Lo = (0.3 / d ** 0.5) * torch.randn(n, d, d, **kw)       # Lo[i] = L[lo+i+1, lo+i]
+    xt = torch.randn(n, d, **kw)
+    edge = torch.cat([Ld[-1].reshape(-1), Lo[-1].reshape(-1), xt[-1], xt[0]]).contiguous()
+    if world > 1:
+        flat = torch.empty(world * edge.numel(), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(flat, edge, group=group)
+        edges = flat.view(world, edge.numel())
+    else:
+        edges = edge[None]
+    dd = d * d
+    Rs = Ld @ Ld.transpose(-1, -2)
+    Rs[1:] += Lo[:-1] @ Lo[:-1].transpose(-1, -2)
+    Os_all = Lo @ Ld.transpose(-1, -2)                       # Os_all[i] = J[lo+i+1, lo+i]
+    O_left = None
+    if rank > 0:
+        pLd, pLo = edges[rank - 1, :dd].reshape(d, d), edges[rank - 1, dd:2 * dd].reshape(d, d)
+        Rs[0] += pLo @ pLo.T
+        O_left = pLo @ pLd.T
+    b = torch.einsum("nij,nj->ni", Rs, xt)
+    b[1:] += torch.einsum("nij,nj->ni", Os_all[:-1], xt[:-1])
+    b[:-1] += torch.einsum("nji,nj->ni", Os_all[:-1], xt[1:])
+    if rank > 0:
+        b[0] += O_left @ edges[rank - 1, 2 * dd:2 * dd + d]
+    if rank < world - 1:
+        b[-1] += Os_all[-1].T @ edges[rank + 1, 2 * dd + d:2 * dd + 2 * d]
+    local = torch.stack([(xt * b).sum(), 2.0 * _sum_log_abs_det(Ld)])
+    if world > 1:
+        dist.all_reduce(local, group=group)
+    O_left = None if O_left is None else O_left.to(dtype).contiguous()
+    return (Rs.to(dtype).contiguous(), Os_all[:-1].to(dtype).contiguous(), b.to(dtype).contiguous(), O_left,
+            float(local[0]), float(local[1]))
+
+
+def _sum_log_abs_det(A):
+    """sum_i log|det A_i| by unpivoted elimination vectorised over the batch (blocks are
+    1.5 I + small noise); plain tensor ops, runs on any device."""
+    A = A.clone()
+    d = A.shape[-1]
+    total = torch.zeros((), dtype=A.dtype, device=A.device)
+    for j in range(d):
+        piv = A[:, j, j]
+        total = total + torch.log(piv.abs()).sum()
+        if j + 1 < d:
+            A[:, j + 1:, :] -= (A[:, j + 1:, j:j + 1] / piv[:, None, None]) * A[:, j:j + 1, :]
+    return total

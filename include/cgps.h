@@ -112,6 +112,30 @@ int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype,
 int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
                         void* Sd, void* So, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- time-axis sharding (one shard per GPU / rank) -----------------------------------------
+ * The reference has no distributed code; this is the multi-GPU form BASELINE.json asks for.
+ * A shard is n_loc consecutive block rows: Rs[n_loc], Os[n_loc-1] (couplings INSIDE the shard),
+ * x[n_loc], plus O_left = J[first row of the shard, last row of the previous shard] (NULL for the
+ * first shard).  cgps_shard_reduce eliminates every row of the shard but its last one and leaves
+ *   record_out  : cgps_record_elems() elements = that last row (R, y), its new coupling to the
+ *                 previous shard's last row, and the additive update it owes that row;
+ *   partial_out : 4 doubles {sum of squares, sum of log pivots, 1 + first failing LOCAL row or 0, 0}.
+ * The caller gathers the P records and partials in shard order (ONE all-gather over RCCL; the
+ * library itself never communicates) and every rank calls cgps_finish_records, which reduces
+ * the P-row boundary system and writes out2 = {mahal, logdet} and info (1 + a failing row --
+ * local to the shard that saw it -- or 0).  record_stride_bytes / partial_stride_bytes are the
+ * distances between consecutive shards' records / partials, so both can be read in place from
+ * the receive buffer of an all-gather of [record | partial] messages (record_out and
+ * partial_out of cgps_shard_reduce may point straight into the send buffer; partial_out must
+ * be 8-byte aligned).  P <= 2048.  Built for fp64 d <= 4 and fp32 d <= 5
+ * (CGPS_ERR_UNSUPPORTED otherwise). */
+int cgps_record_elems(int d, int dtype, int64_t* elems);
+int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void* O_left, int64_t n_loc, int d,
+                      int dtype, void* ws, size_t ws_bytes, void* record_out, double* partial_out, void* stream);
+int cgps_finish_records(const void* records, size_t record_stride_bytes, const double* partials,
+                        size_t partial_stride_bytes, int64_t P, int64_t rows_per_shard, int64_t N_total, int d,
+                        int dtype, double* out2, int* info, void* stream);
+
 /* Measurement hook (bench.py): the next cgps_mahal_logdet call on this host thread
  * records `start` right before and `stop` right after its dominant kernel (the one
  * that streams Rs/Os/x from HBM) on the call's stream, then the hook clears itself.

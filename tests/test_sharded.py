@@ -1,0 +1,156 @@
+"""Time-axis sharding (cyclic_gps/sharded.py).
+
+CPU: shard bookkeeping, the record algebra against the oracle, and the collective path with
+world_size 2 and 3 under gloo (device steps replaced by the dense stand-in of _shard_dense.py).
+GPU: the HIP shard records against the dense records, and the full sharded result on one GPU.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _util
+import _shard_dense as SD
+from oracle import cr_oracle as O
+from cyclic_gps import sharded
+
+
+def _split(Rs, Os, x, bounds):
+    """Shards of a whole system: (Rs, Os_inside, x, O_left) per [lo, hi)."""
+    out = []
+    for lo, hi in bounds:
+        out.append((Rs[lo:hi], Os[lo:hi - 1], x[lo:hi], Os[lo - 1] if lo > 0 else None))
+    return out
+
+
+def test_shard_bounds_cover_the_axis():
+    for n in (1, 2, 7, 64, 1000, 2 ** 20 + 3):
+        for world in (1, 2, 3, 8):
+            if world > n:
+                continue
+            b = [sharded.shard_bounds(n, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("d,n,parts", [(1, 9, 3), (2, 17, 2), (3, 40, 5), (4, 33, 4), (3, 5, 5)])
+def test_record_algebra_against_oracle(d, n, parts):
+    """Reducing every shard to its record and finishing the boundary system gives exactly the
+    oracle's mahal_and_det of the whole system (shards of one row included)."""
+    Rs, Os, b, _, _ = _util.conditioned_system(n, d, seed=5 + n)
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    recs, parts_ = [], []
+    for sR, sO, sx, Ol in _split(Rs, Os, b, bounds):
+        r, p = SD.dense_shard_record(sR.numpy(), sO.numpy(), sx.numpy(), None if Ol is None else Ol.numpy())
+        # through the packed layout, as it travels
+        recs.append(SD.unpack_record(SD.pack_record(r, d), d))
+        parts_.append(p)
+    m, ld = SD.dense_finish(recs, parts_, d)
+    m0, ld0 = O.mahal_and_det(Rs, Os, b)
+    np.testing.assert_allclose([m, ld], [float(m0), float(ld0)], rtol=1e-10)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, n_total, d, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(
+            n_total, d, torch.float64, torch.device("cpu"), rank, world)
+        lo, hi = sharded.shard_bounds(n_total, world, rank)
+        assert Rs.shape[0] == hi - lo and Os.shape[0] == hi - lo - 1
+        assert (O_left is None) == (rank == 0)
+        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world, ops=SD.DenseShardOps(d))
+        out = plan.run().clone()
+        # every rank must hold the same result
+        outs = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(outs, out)
+        # rebuild the whole system on rank 0 and run the oracle on it
+        full = [None] * world
+        dist.all_gather_object(full, (Rs, Os, b, O_left))
+        if rank == 0:
+            R = torch.cat([f[0] for f in full])
+            parts = []
+            for r, f in enumerate(full):
+                if r > 0:
+                    parts.append(f[3][None])
+                parts.append(f[1])
+            Oall = torch.cat(parts)
+            x = torch.cat([f[2] for f in full])
+            m0, ld0 = O.mahal_and_det(R, Oall, x)
+            q.put(dict(outs=[o.tolist() for o in outs], oracle=[float(m0), float(ld0)],
+                       closed=[mahal_true, logdet_true]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,d", [(2, 257, 3), (3, 100, 2), (2, 2, 4)])
+def test_collective_path_under_gloo(world, n_total, d):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_gloo_worker, args=(world, _free_port(), n_total, d, q), nprocs=world, join=True)
+    res = q.get()
+    for o in res["outs"]:
+        np.testing.assert_allclose(o, res["outs"][0], rtol=0, atol=0)
+    np.testing.assert_allclose(res["outs"][0], res["oracle"], rtol=1e-10)
+    np.testing.assert_allclose(res["outs"][0], res["closed"], rtol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float64), (4, torch.float64),
+                                     (4, torch.float32), (5, torch.float32)])
+@pytest.mark.parametrize("n,parts", [(7, 3), (64, 2), (300, 3), (1000, 3), (5000, 4), (16385, 2), (40000, 5)])
+def test_hip_shard_records_match_dense(d, dtype, n, parts):
+    from cyclic_gps import _hip
+    import ctypes
+    Rs, Os, b, _, _ = _util.conditioned_system(n, d, seed=11 + n)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=3e-4, atol=3e-4)
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    rec_bytes, msg_bytes = sharded.message_layout(d, dtype)
+    recv = torch.zeros(parts * msg_bytes, dtype=torch.uint8, device="cuda")
+    for r, (sR, sO, sx, Ol) in enumerate(_split(Rs, Os, b, bounds)):
+        ops = sharded.HipShardOps(sR.shape[0], d, dtype, torch.device("cuda"))
+        send = recv[r * msg_bytes:(r + 1) * msg_bytes]
+        ops.shard_reduce(sR.to(dtype).cuda().contiguous(), sO.to(dtype).cuda().contiguous(),
+                         sx.to(dtype).cuda().contiguous(), None if Ol is None else Ol.to(dtype).cuda().contiguous(),
+                         send, rec_bytes)
+        gp = send[rec_bytes:].view(torch.float64).cpu().numpy()
+        assert gp[2] == 0.0
+        if sR.shape[0] * d > 1500:            # dense algebra is O(n^3): element-wise record check on small shards
+            continue
+        rec, par = SD.dense_shard_record(sR.numpy(), sO.numpy(), sx.numpy(), None if Ol is None else Ol.numpy())
+        used = 3 * d * d + 2 * d              # the rest of the stride is alignment padding
+        got = send[:rec_bytes].view(dtype).cpu().double().numpy()[:used]
+        np.testing.assert_allclose(got, SD.pack_record(rec, d)[:used], err_msg="shard %d" % r, **tol)
+        np.testing.assert_allclose(gp[:2], par[:2], rtol=tol["rtol"], atol=1e-8 if dtype == torch.float64 else 1e-2)
+    out = torch.zeros(2, dtype=torch.float64, device="cuda")
+    ops.finish(recv, parts, rec_bytes, msg_bytes, bounds[0][1] - bounds[0][0], n, out)
+    m0, ld0 = O.mahal_and_det(Rs, Os, b)
+    np.testing.assert_allclose(out.cpu().numpy(), [float(m0), float(ld0)],
+                               rtol=1e-9 if dtype == torch.float64 else 2e-4)
+    assert int(ops.info.item()) == 0
+
+
+@pytest.mark.gpu
+def test_sharded_plan_world1_on_gpu():
+    n, d = 70000, 4
+    Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(
+        n, d, torch.float64, torch.device("cuda"), 0, 1)
+    plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n, 0, 1)
+    out = plan.run().cpu().numpy()
+    np.testing.assert_allclose(out, [mahal_true, logdet_true], rtol=1e-10)
+    assert int(plan.ops.info.item()) == 0
