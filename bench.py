@@ -66,12 +66,67 @@ def cpu_baseline(n, d, dtype, reps=3):
                       % (n, d, str(dtype).replace("torch.", ""), reps, torch.__version__)}
 
 
+def _time_cuda(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def extra_measurements(dev):
+    """Secondary numbers of SURVEY.md 8(d), outside the timed region of the headline metric:
+    Op B (decompose + solve + det through the module surface, N=2^20 d=4 fp64), BASELINE
+    config 3 (N=2^22 d=8 fp32) and config 4's single-GPU point (N=2^24 d=4 fp64)."""
+    import cyclic_gps.cyclic_reduction as cr
+    cr.CHECK_POSITIVE_DEFINITE = False          # no device->host sync inside the timed calls
+    out = {}
+    for name, n, d, dtype, reps in (("opB_N2^20_d4_f64", 1 << 20, 4, torch.float64, 10),
+                                    ("c3_N2^22_d8_f32", 1 << 22, 8, torch.float32, 3),
+                                    ("c4_N2^24_d4_f64_1gpu", 1 << 24, 4, torch.float64, 5)):
+        try:
+            Rs, Os, b, x_true, logdet_true = make_system(n, d, dtype, dev)
+            s = Rs.element_size()
+            res = {}
+            t = _time_cuda(lambda: cr.mahal_and_det(Rs, Os, b), reps)
+            res["mahal_and_det_us"] = t * 1e6
+            res["mahal_and_det_GBps"] = algorithmic_bytes(n, d, s) / t / 1e9
+            m, ld = cr.mahal_and_det(Rs, Os, b)
+            res["logdet_rel_err"] = abs(float(ld) - logdet_true) / abs(logdet_true)
+            if not name.startswith("c4"):
+                holder = {}
+
+                def dec():
+                    holder["dec"] = cr.decompose(Rs, Os)
+                t_dec = _time_cuda(dec, reps)
+                t_sol = _time_cuda(lambda: cr.solve(holder["dec"], b), reps)
+                t_det = _time_cuda(lambda: cr.det(holder["dec"]), reps)
+                xs = cr.solve(holder["dec"], b)
+                res.update(decompose_us=t_dec * 1e6, solve_us=t_sol * 1e6, det_us=t_det * 1e6,
+                           decompose_GBps=5.0 * n * d * d * s / t_dec / 1e9,
+                           solve_GBps=(3.0 * n * d * d + 2.0 * n * d) * s / t_sol / 1e9,
+                           factor_solves_per_s=1.0 / (t_dec + t_sol),
+                           solve_max_abs_err=float((xs.double() - x_true.double()).abs().max()))
+                del holder, xs
+            out[name] = res
+            del Rs, Os, b, x_true
+            torch.cuda.empty_cache()
+        except Exception as e:  # keep the headline line alive whatever happens here
+            out[name] = {"error": repr(e)[:200]}
+    cr.CHECK_POSITIVE_DEFINITE = True
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary (Op B / config 3 / 2^24) numbers")
     ap.add_argument("--levelwise", action="store_true", help="time the one-launch-per-level form instead")
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="block rows per GPU")
     ap.add_argument("--d", type=int, default=D)
@@ -201,6 +256,18 @@ def main():
                      "ms_per_step_with_event_hooks": elapsed_with_events / args.steps * 1e3},
         "check": {"logdet_rel_err": rel_ld, "mahal_rel_err": rel_m},
     }
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+    # the number comes from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, calibrated as the guide says)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise:
+            line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json"
+    except Exception:
+        pass
+    if world == 1 and not args.no_extras:
+        line["extras"] = extra_measurements(dev)
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
     else:

@@ -14,15 +14,17 @@
 //    chunk's own last row (kept: R_s, y_s and C_s = its new coupling to the
 //    previous chunk's last row) and that previous row (additive update dRa,
 //    dya).  No lane idles and nothing but the inputs crosses HBM.
-//  stage 2, tile_cr: the NT boundary rows of a workgroup form a block
-//    tridiagonal system in LDS that is reduced by even/odd cyclic reduction
-//    (log2 NT levels, one elimination per lane and one barrier per level) to ONE
+//  stage 2, tile_cr: the kept rows of a workgroup's lanes form a block
+//    tridiagonal system in LDS that is reduced by even/odd cyclic reduction to ONE
 //    boundary row + the update for the previous workgroup's boundary row: a
-//    "record".
+//    "record".  The levels are latency-bound (a lone wave issues one fp64 op per
+//    ~8 cycles), so one elimination's ~480 fp64 instructions are split over FOUR
+//    waves by role (left-neighbour products / right-neighbour update / two halves
+//    of the new coupling block): the operands are in LDS anyway, no shuffles.
 //  stage 3, record_reduce_kernel: records are rows of a (N / (C NT))-row system;
 //    the same tile_cr reduces them (recursively for very large N) and the last
-//    launch eliminates the final row, sums the partial log-det / mahal and
-//    writes the info word.
+//    launch eliminates the final row, sums the partial log-det / mahal in a
+//    fixed order and writes the info word.
 //
 // Ragged sizes are exact, no padding rows: a short chunk / tile simply keeps its
 // last REAL row, which is what lets a shard of a larger system (one per GPU) be
@@ -32,11 +34,11 @@
 
 namespace cgps {
 
-// ---- LDS tile of NT block rows -------------------------------------------------------
-//   R[NT][DD], y[NT][D]  : the rows; a slot whose row has been eliminated is reused for the
-//                          update that elimination owes its LEFT neighbour (see tile_cr)
-//   Oc[NT+1][DD]         : Oc[i+1] = J[next active row, row i]; Oc[0] = J[first active row,
-//                          row left of the tile]
+// ---- LDS tile of NTILE block rows ------------------------------------------------------
+//   R[NTILE][DD], y[NTILE][D] : the rows; a slot whose row has been eliminated is reused for
+//                               the update that elimination owes its LEFT neighbour
+//   Oc[NTILE+1][DD]           : Oc[i+1] = J[next active row, row i]; Oc[0] = J[first active
+//                               row, row left of the tile]
 // 16-byte granules of a block are XOR-swizzled by a fold of the row index so that the
 // strided row access of every reduction level spreads over the LDS banks.
 template <typename T, int D>
@@ -88,6 +90,20 @@ struct LdsTile {
       store_block<T, D>(base + (size_t)row * DD, A);
     }
   }
+  // rows [r0, r1) of a block, element by element (two waves may write disjoint rows of one block)
+  template <int R0, int R1>
+  static __device__ __forceinline__ void store_rows(T* base, int row, const T (&A)[D][D]) {
+    T* p = base + (size_t)row * DD;
+    const int kk = SWZ ? key(row) : 0;
+#pragma unroll
+    for (int i = R0; i < R1; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int idx = i * D + j;
+        if constexpr (SWZ) p[((idx / VN) ^ kk) * VN + (idx % VN)] = A[i][j];
+        else p[idx] = A[i][j];
+      }
+  }
   __device__ __forceinline__ void carve(char* smem, int nt) {
     R = reinterpret_cast<T*>(smem);
     Oc = R + (size_t)nt * DD;
@@ -97,10 +113,10 @@ struct LdsTile {
 
 // bytes of the LDS tile + block-reduction scratch + wave-exchange scratch + fail word
 template <typename T, int D>
-constexpr size_t stage_lds_bytes(int nt) {
-  size_t tile = ((size_t)nt * (2 * D * D + D) + D * D) * sizeof(T);
+constexpr size_t stage_lds_bytes(int ntile, int nthr) {
+  size_t tile = ((size_t)ntile * (2 * D * D + D) + D * D) * sizeof(T);
   tile = (tile + 15) & ~(size_t)15;
-  return tile + 2 * (nt / 64) * sizeof(double) + (size_t)(nt / 64) * (D * D + D) * sizeof(T) + 64;
+  return tile + 2 * (nthr / 64) * sizeof(double) + (size_t)(nthr / 64) * (D * D + D) * sizeof(T) + 64;
 }
 
 // Running product of pivots with a rare fold into a log sum: one log() per lane
@@ -115,13 +131,6 @@ struct PivotLog {
 };
 
 template <typename T, int D>
-__device__ __forceinline__ void set_identity(T (&A)[D][D]) {
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) A[i][j] = (i == j) ? T(1) : T(0);
-}
-template <typename T, int D>
 __device__ __forceinline__ void set_zero(T (&A)[D][D]) {
 #pragma unroll
   for (int i = 0; i < D; ++i)
@@ -133,7 +142,7 @@ __device__ __forceinline__ void set_zero(T (&v)[D]) {
 #pragma unroll
   for (int i = 0; i < D; ++i) v[i] = T(0);
 }
-// lower(S) = A A^T (fresh)
+// lower(S) = A A^T (fresh), upper part zero
 template <typename T, int D>
 __device__ __forceinline__ void syrk_lower(T (&S)[D][D], const T (&A)[D][D]) {
 #pragma unroll
@@ -178,95 +187,175 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
   }
 }
 
-// Even/odd cyclic reduction of the NT-row system in the LDS tile, in place; rows of level l
-// live at slots (m+1) 2^l - 1 (cf. decompose_step, cyclic_reduction.py:225-254).
-// Thread k < NT / 2^(l+1) eliminates the even row e = (2k+1) s - 1, s = 2^l:
-//   D = chol(R_e), x = D^-1 y_e, G = Oc[l]^T D^-T (left neighbour l = e - s, or the row left of
-//   the tile for k = 0), F = Oc[e] D^-T (right neighbour o = e + s);
+// Even/odd cyclic reduction of the n_real-row system in the LDS tile, in place; rows of level
+// l live at slots (m+1) 2^l - 1 (cf. decompose_step, cyclic_reduction.py:225-254).
+// Elimination k of a level removes the even row e = (2k+1) s - 1, s = 2^l, between its left
+// neighbour l = e - s (or the row left of the tile for k = 0) and right neighbour o:
+//   D = chol(R_e), x = D^-1 y_e, G = Oc[l]^T D^-T, F = Oc[e] D^-T
 //   right neighbour:  R_o -= F F^T, y_o -= F x            (applied now)
 //   left neighbour :  owes G G^T, G x                      (parked in the dead slot e and taken
-//                      off row l = e - s by whoever touches that row at the next level, where
-//                      its parking slot is exactly l + (2s)/2 = e)
+//                      off row l by whoever touches that row at the next level, where its
+//                      parking slot is exactly l + (2s)/2 = e)
 //   new coupling   :  Oc[l] = -F G^T  (J[o, l])
-// so every lane does ONE elimination per level and there is one barrier per level.
-// Ragged tiles (n_real <= NT rows) are exact: the tile's LAST real row K = n_real - 1 is never
-// eliminated (it is the boundary the next tile / shard couples to), which is the reference's
-// odd/even size rule (cyclic_reduction.py:240-248, 262-280) with the last row always kept: at
-// a level with M = (K+1)/s regular rows, thread k eliminates regular row 2k unless it is K, and
-// its right neighbour is regular row 2k+1, or K when 2k is the last regular row.
+// Ragged tiles are exact: the LAST real row K = n_real - 1 is never eliminated (it is the
+// boundary the next tile / shard couples to) -- the reference's odd/even size rule
+// (cyclic_reduction.py:240-248, 262-280) with the last row always kept: at a level with
+// M = (K+1)/s regular rows, regular row 2k is eliminated unless it is K, and its right
+// neighbour is regular row 2k+1, or K when 2k is the last regular row.
+//
+// Work split: wave w plays role w % 4 for eliminations 64 * (w / 4 + (NTHR/256) * iter) + lane:
+//   role 0  x, G, parks G G^T and G x, accumulates log-det and mahal
+//   role 1  x, F, updates the right neighbour
+//   role 2  G, F rows [0, D/2): rows [0, D/2) of the new coupling
+//   role 3  G, F rows [D/2, D): the other rows
+// (every role factors R_e itself: 1/8 of the instructions, no exchange).  All roles read, then
+// a barrier, then they write, then a barrier.
 // On return slot K holds the tile's boundary row, Oc[0] its coupling to the row left of the
 // tile and the slots 2^l - 1 of the executed levels what is owed to that row; returns the
 // number of executed levels.
-template <typename T, int D, int NT>
-__device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail) {
+// dev-only: clock stamps per (level pass, wave, phase); no stamp executes in the library build
+#ifdef CGPS_TILE_STAMPS
+// stamps live in LDS (a global store here would sit in the vm queue the next barrier drains);
+// slot layout [pass][wave][4 phases][2 clocks: shader cycles, 100 MHz wall]
+#define CGPS_STAMP(slot)                                                                         \
+  do {                                                                                           \
+    if (stamps && lane == 0) {                                                                   \
+      unsigned* sp_ = reinterpret_cast<unsigned*>(stamps) + (((size_t)stamp_pass * (NTHR / 64) + wave) * 4 + (slot)) * 2; \
+      sp_[0] = (unsigned)clock64();                                                              \
+      sp_[1] = (unsigned)wall_clock64();                                                         \
+    }                                                                                            \
+  } while (0)
+#else
+#define CGPS_STAMP(slot) do { } while (0)
+#endif
+
+template <typename T, int D, int NTHR>
+__device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
+                                       long long* stamps = nullptr) {
+  int stamp_pass = 0;
+  (void)stamp_pass;
+  static_assert(NTHR % 256 == 0, "tile_cr wants a multiple of four waves");
   using LT = LdsTile<T, D>;
-  const int k = threadIdx.x;
+  constexpr int NGRP = NTHR / 256;              // 64-elimination groups handled per pass
+  constexpr int DH = (D + 1) / 2;               // rows of the new coupling done by role 2
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int role = wave & 3, grp = wave >> 2;
   const int K = n_real - 1;
   int levels = 0;
 #pragma unroll 1
   for (int s = 1; (s - 1) < K; s <<= 1, ++levels) {
-    const int M = (K + 1) / s;
-    const int e = (2 * k + 1) * s - 1;
-    if (2 * k < M && e != K) {
-      const int o = (2 * k + 1 < M) ? e + s : K, h = s >> 1;
-      T A[D][D], x[D];
-      LT::load_blk(t.R, e, A);
-      load_vec<T, D>(t.y + e * D, x);
-      if (s > 1 && e + h < K) {
-        T P[D][D], p[D];
-        LT::load_blk(t.R, e + h, P);
-        load_vec<T, D>(t.y + (e + h) * D, p);
+    const int M = (K + 1) / s, h = s >> 1;
+    const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
+#pragma unroll 1
+    for (int k0 = 0; k0 < n_elim; k0 += 64 * NGRP) {
+      const int k = k0 + 64 * grp + lane;
+      const int e = (2 * k + 1) * s - 1;
+      const bool act = (2 * k < M) && (e != K);
+      const int o = (2 * k + 1 < M) ? e + s : K;
+      // results a role carries across the barrier
+      T W[D][D], wv[D];                          // role 0: parked update; role 1: new R_o, y_o; roles 2/3: new coupling
+      CGPS_STAMP(0);
+      if (act) {
+        T A[D][D];
+        LT::load_blk(t.R, e, A);
+        const bool pend_e = (s > 1) && (e + h < K);
+        if (pend_e) {
+          T P[D][D];
+          LT::load_blk(t.R, e + h, P);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-          x[i] -= p[i];
+          for (int i = 0; i < D; ++i)
 #pragma unroll
-          for (int j = 0; j <= i; ++j) A[i][j] -= P[i][j];
+            for (int j = 0; j <= i; ++j) A[i][j] -= P[i][j];
+        }
+        Chol<T, D> c;
+        bool f = false;
+        const double piv = chol_lower<T, D>(A, c, f);
+        T x[D];
+        if (role < 2) {
+          load_vec<T, D>(t.y + e * D, x);
+          if (pend_e) {
+            T p[D];
+            load_vec<T, D>(t.y + (e + h) * D, p);
+#pragma unroll
+            for (int i = 0; i < D; ++i) x[i] -= p[i];
+          }
+          fwd_subst<T, D>(c, x);
+        }
+        if (role == 0) {
+          pl.mul(piv);
+          fail = fail || f;
+#pragma unroll
+          for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+          T Ol[D][D], G[D][D];
+          LT::load_blk(t.Oc, e - s + 1, Ol);
+          rsolve_lt_transposed<T, D>(c, Ol, G);
+          syrk_lower<T, D>(W, G);
+          set_zero<T, D>(wv);
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int m = 0; m < D; ++m) wv[i] = __builtin_fma(G[i][m], x[m], wv[i]);
+        } else if (role == 1) {
+          T F[D][D];
+          LT::load_blk(t.Oc, e + 1, F);
+          rsolve_lt<T, D>(c, F);
+          LT::load_blk(t.R, o, W);
+          load_vec<T, D>(t.y + o * D, wv);
+          if ((s > 1) && (o + h < K)) {
+            T P[D][D], p[D];
+            LT::load_blk(t.R, o + h, P);
+            load_vec<T, D>(t.y + (o + h) * D, p);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+              wv[i] -= p[i];
+#pragma unroll
+              for (int j = 0; j <= i; ++j) W[i][j] -= P[i][j];
+            }
+          }
+          syrk_sub_lower<T, D>(W, F);
+          gemv_sub<T, D>(wv, F, x);
+          mirror_lower<T, D>(W);
+        } else {
+          T Ol[D][D], G[D][D], F[D][D];
+          LT::load_blk(t.Oc, e - s + 1, Ol);
+          rsolve_lt_transposed<T, D>(c, Ol, G);
+          LT::load_blk(t.Oc, e + 1, F);
+          const int i0 = (role == 2) ? 0 : DH, i1 = (role == 2) ? DH : D;
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            if (i >= i0 && i < i1) {
+              fwd_subst<T, D>(c, F[i]);           // row i of F = Oc[e] D^-T
+#pragma unroll
+              for (int j = 0; j < D; ++j) {
+                T sacc = T(0);
+#pragma unroll
+                for (int m = 0; m < D; ++m) sacc = __builtin_fma(-F[i][m], G[j][m], sacc);
+                W[i][j] = sacc;
+              }
+            }
+          }
         }
       }
-      Chol<T, D> c;
-      pl.mul(chol_lower<T, D>(A, c, fail));
-      fwd_subst<T, D>(c, x);
-#pragma unroll
-      for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
-      T Ol[D][D], G[D][D], F[D][D];
-      LT::load_blk(t.Oc, e - s + 1, Ol);
-      rsolve_lt_transposed<T, D>(c, Ol, G);
-      LT::load_blk(t.Oc, e + 1, F);
-      rsolve_lt<T, D>(c, F);
-      // right neighbour
-      T Ro[D][D], yo[D];
-      LT::load_blk(t.R, o, Ro);
-      load_vec<T, D>(t.y + o * D, yo);
-      if (s > 1 && o + h < K) {
-        T P[D][D], p[D];
-        LT::load_blk(t.R, o + h, P);
-        load_vec<T, D>(t.y + (o + h) * D, p);
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-          yo[i] -= p[i];
-#pragma unroll
-          for (int j = 0; j <= i; ++j) Ro[i][j] -= P[i][j];
+      CGPS_STAMP(1);
+      __syncthreads();                            // every role has read its operands
+      CGPS_STAMP(2);
+      if (act) {
+        if (role == 0) {
+          LT::store_blk(t.R, e, W);
+          store_vec<T, D>(t.y + e * D, wv);
+        } else if (role == 1) {
+          LT::store_blk(t.R, o, W);
+          store_vec<T, D>(t.y + o * D, wv);
+        } else if (role == 2) {
+          LT::template store_rows<0, DH>(t.Oc, e - s + 1, W);
+        } else {
+          LT::template store_rows<DH, D>(t.Oc, e - s + 1, W);
         }
       }
-      syrk_sub_lower<T, D>(Ro, F);
-      gemv_sub<T, D>(yo, F, x);
-      mirror_lower<T, D>(Ro);
-      LT::store_blk(t.R, o, Ro);
-      store_vec<T, D>(t.y + o * D, yo);
-      // what the left neighbour is owed, parked in slot e
-      T W[D][D], wv[D];
-      syrk_lower<T, D>(W, G);
-      set_zero<T, D>(wv);
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int m = 0; m < D; ++m) wv[i] = __builtin_fma(G[i][m], x[m], wv[i]);
-      LT::store_blk(t.R, e, W);
-      store_vec<T, D>(t.y + e * D, wv);
-      neg_abt<T, D>(Ol, F, G);
-      LT::store_blk(t.Oc, e - s + 1, Ol);
+      __syncthreads();                            // the level's results are visible
+      CGPS_STAMP(3);
+      ++stamp_pass;
     }
-    __syncthreads();
   }
   return levels;
 }
@@ -320,7 +409,7 @@ __device__ __forceinline__ void write_partial(double mah, double logp, int failr
 
 // The update a lane computed for the row left of its chunk belongs to the previous lane's
 // kept row: fetch it from lane+1 (wave-local shuffle; LDS across the wave boundary) and add it.
-// The tile's last lane keeps its row as is (its update arrives with the next tile's record).
+// The tile's last real lane keeps its row as is (its update arrives with the next tile's record).
 template <typename T, int D, int NT>
 __device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (&yc)[D], const T (&dRa)[D][D],
                                                               const T (&dya)[D], T* xch, int n_real) {
@@ -367,14 +456,13 @@ __device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (
 }
 
 // Common second half of both kernels: the lanes' kept rows -> LDS tile -> cyclic reduction ->
-// this tile's record (thread 0).  Returns the number of executed levels.
+// this tile's record (thread 0).  Lanes >= n_real carry nothing (zero updates, not stored).
 template <typename T, int D, int NT>
 __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D][D], T (&yc)[D], T (&Cc)[D][D],
                                                      T (&dRa)[D][D], T (&dya)[D], int n_real, T* xch,
                                                      T* __restrict__ rec_out, PivotLog& pl, double& mah, bool& fail) {
   using RL = RecordLayout<T, D>;
   const int tid = threadIdx.x;
-  // lanes past the tile's real rows carry nothing (zero updates, never stored or read)
   absorb_right_neighbour_update<T, D, NT>(Rc, yc, dRa, dya, xch, n_real);
   if (tid < n_real) {
     mirror_lower<T, D>(Rc);
@@ -400,7 +488,7 @@ __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D
   }
 }
 
-template <typename T, int D, int NT>
+template <typename T, int D, int NTILE, int NT>
 struct StageSmem {
   static constexpr int DD = D * D;
   LdsTile<T, D> t;
@@ -408,8 +496,8 @@ struct StageSmem {
   T* xch;
   int* sfail;
   __device__ __forceinline__ StageSmem(char* smem) {
-    t.carve(smem, NT);
-    char* tail = smem + ((((size_t)NT * (2 * DD + D) + DD) * sizeof(T) + 15) & ~(size_t)15);
+    t.carve(smem, NTILE);
+    char* tail = smem + ((((size_t)NTILE * (2 * DD + D) + DD) * sizeof(T) + 15) & ~(size_t)15);
     red = reinterpret_cast<double*>(tail);
     xch = reinterpret_cast<T*>(red + 2 * (NT / 64));        // [NT/64][DD + D] wave-boundary exchange
     sfail = reinterpret_cast<int*>(xch + (NT / 64) * (DD + D));
@@ -426,7 +514,7 @@ __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ 
   // first row of the whole system.
   constexpr int DD = D * D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  StageSmem<T, D, NT> sm(smem);
+  StageSmem<T, D, NT, NT> sm(smem);
   const int tid = threadIdx.x;
   if (tid == 0) *sm.sfail = 0x7fffffff;
   const int64_t lane0 = (int64_t)blockIdx.x * NT;
@@ -469,12 +557,13 @@ __global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ 
 // ---- stage 3 -----------------------------------------------------------------------------
 // Records in -> records out (FINAL = false), or -> out2 = {mahal, logdet} and info (FINAL =
 // true, one workgroup).  Row w of this stage: R = Rs[w] + dRa[w+1], y = ys[w] + dya[w+1],
-// coupling to row w-1: Cs[w].  Each lane first eliminates rc consecutive rows left to right
-// (like stage 1), then the workgroup reduces the NT kept rows.
+// coupling to row w-1: Cs[w].  Lane t < NTILE first eliminates its rc consecutive rows left to
+// right (like stage 1); then all NT lanes (NT >= NTILE: the extra waves only add hands to
+// tile_cr) reduce the NTILE kept rows.  rstride / pstride: distance between consecutive
+// records (elements of T) / partials (doubles).
 template <typename T, int D>
 __device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64_t rstride, int64_t w, int64_t n,
-                                                bool add_next,
-                                                T (&R)[D][D], T (&y)[D], T (&Cs)[D][D]) {
+                                                bool add_next, T (&R)[D][D], T (&y)[D], T (&Cs)[D][D]) {
   using RL = RecordLayout<T, D>;
   if (w < n) {
     const T* r = rin + (size_t)w * rstride;
@@ -500,7 +589,7 @@ __device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64
   }
 }
 
-template <typename T, int D, int NT, bool FINAL>
+template <typename T, int D, int NTILE, int NT, bool FINAL>
 __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__ rin, int64_t n, int rc,
                                                            T* __restrict__ rout, double* __restrict__ partial_out,
                                                            const double* __restrict__ partial_in, int64_t n_partial,
@@ -509,14 +598,14 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
                                                            int64_t pstride) {
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  StageSmem<T, D, NT> sm(smem);
+  StageSmem<T, D, NTILE, NT> sm(smem);
   const int tid = threadIdx.x;
   if (tid == 0) *sm.sfail = 0x7fffffff;
-  const int64_t w0 = (int64_t)blockIdx.x * NT * rc;       // first record of this tile
-  int64_t wend = w0 + (int64_t)NT * rc;
+  const int64_t w0 = (int64_t)blockIdx.x * NTILE * rc;    // first record of this tile
+  int64_t wend = w0 + (int64_t)NTILE * rc;
   if (wend > n) wend = n;
   const int64_t wlast = wend - 1;                         // its last one (kept; its update is deferred)
-  const int64_t wb = w0 + (int64_t)tid * rc;
+  const int64_t wb = (tid < NTILE) ? w0 + (int64_t)tid * rc : n;
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
@@ -537,7 +626,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
   const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
-  const int n_real = nthreads_real > NT ? NT : (int)nthreads_real;
+  const int n_real = nthreads_real > NTILE ? NTILE : (int)nthreads_real;
   reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah,
                                  fail);
   int64_t frow = (wb + rc) * rows_per_record;
@@ -575,25 +664,6 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   }
 }
 
-// ---- host side ------------------------------------------------------------------------------
-template <typename T, int D> constexpr bool tile_supported() {
-  return (sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5);
-}
-template <typename T, int D> struct TileCfg {
-  static constexpr int C = 16;       // rows per lane in stage 1
-  static constexpr int NT1 = 64;     // lanes per workgroup in stage 1 (one wave: no cross-wave barriers)
-  static constexpr int NT3 = 512;    // lanes per workgroup in stage 3
-  static constexpr int RCMAX = 4;    // records a stage-3 lane eliminates sequentially before the LDS reduction
-};
-constexpr int64_t TILE_ROWS_MIN = 16 * 64;   // smallest rows-per-tile over all TileCfg (workspace sizing)
-
-inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
-  const int64_t tiles = N / TILE_ROWS_MIN + 2;
-  const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
-  const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
-  return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
-}
-
 // {sum, sum, smallest non-zero, 0} over per-block partial results
 __global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __restrict__ partial, int64_t count,
                                                             double* __restrict__ out4) {
@@ -617,6 +687,41 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __rest
   }
 }
 
+// ---- host side ------------------------------------------------------------------------------
+template <typename T, int D> constexpr bool tile_supported() {
+  return (sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5);
+}
+template <typename T, int D> struct TileCfg {
+  static constexpr int C = 16;         // rows per lane in stage 1
+  static constexpr int NT1 = 256;      // lanes (= threads) per workgroup in stage 1
+  static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
+  static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
+  static constexpr int RCMAX = 4;      // records a stage-3 lane eliminates sequentially before the LDS reduction
+};
+constexpr int64_t TILE_ROWS_MIN = 16 * 256;   // smallest rows-per-tile over all TileCfg (workspace sizing)
+
+inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
+  const int64_t tiles = N / TILE_ROWS_MIN + 2;
+  const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
+  const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
+  return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
+}
+
+template <typename T, int D>
+void tile_set_attributes() {
+  using Cfg = TileCfg<T, D>;
+  static bool done = false;
+  if (done) return;
+  const int lds1 = (int)stage_lds_bytes<T, D>(Cfg::NT1, Cfg::NT1), lds3 = (int)stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+  done = true;
+}
+
 // The fused pipeline.  Whole system: shard_record == nullptr, results in out2 / info.
 // One shard of a sharded system: shard_record / shard_partial receive the shard's single record
 // and its {mahal, logdet, fail, 0} partial; Oleft = J[first row of the shard, last row of the
@@ -636,17 +741,8 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   T* recA = reinterpret_cast<T*>(ws + pbytes);
   T* recB = recA + (size_t)(tiles_cap + 2) * RL::STRIDE;
-  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NT3);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    attr_done = true;
-  }
+  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NT1, Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
+  tile_set_attributes<T, D>();
   if (ev_start) (void)hipEventRecord(ev_start, st);
   hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                      Rs, Os, x, N, Oleft, recA, partial);
@@ -655,13 +751,13 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   T *rin = recA, *rout = recB;
   // a shard is reduced all the way to ONE record; the whole system stops as soon as the final
   // workgroup can take what is left
-  while (shard_record ? n > 1 : n > (int64_t)Cfg::NT3 * Cfg::RCMAX) {
-    int rc = (int)((n + Cfg::NT3 - 1) / Cfg::NT3);
+  while (shard_record ? n > 1 : n > (int64_t)Cfg::NTILE3 * Cfg::RCMAX) {
+    int rc = (int)((n + Cfg::NTILE3 - 1) / Cfg::NTILE3);
     if (rc > Cfg::RCMAX) rc = Cfg::RCMAX;
-    const int64_t per = (int64_t)Cfg::NT3 * rc;
+    const int64_t per = (int64_t)Cfg::NTILE3 * rc;
     const int64_t g = (n + per - 1) / per;
-    hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3), lds3, st,
-                       (const T*)rin, n, rc, rout, partial + PARTIAL_STRIDE * npart, (const double*)nullptr,
+    hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3),
+                       lds3, st, (const T*)rin, n, rc, rout, partial + PARTIAL_STRIDE * npart, (const double*)nullptr,
                        (int64_t)0, (double*)nullptr, (int*)nullptr, rows_per_record, N, (int64_t)RL::STRIDE,
                        (int64_t)PARTIAL_STRIDE);
     npart += g;
@@ -674,32 +770,28 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     hipLaunchKernelGGL(sum_partials4_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, npart, shard_partial);
     return 0;
   }
-  const int rc = (int)((n + Cfg::NT3 - 1) / Cfg::NT3);
-  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st, (const T*)rin, n,
-                     rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info, rows_per_record, N,
-                     (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+  const int rc = (int)((n + Cfg::NTILE3 - 1) / Cfg::NTILE3);
+  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st,
+                     (const T*)rin, n, rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info,
+                     rows_per_record, N, (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
   return 0;
 }
 
 // Finish a sharded reduction: P shard records (in shard order) + their partial results ->
-// out2 = {mahal, logdet}, info.  One workgroup; P <= NT3 * RCMAX.  rstride / pstride: distance
+// out2 = {mahal, logdet}, info.  One workgroup; P <= NTILE3 * RCMAX.  rstride / pstride: distance
 // between consecutive records (elements of T) / partials (doubles), so both can be read in place
 // from an all-gather receive buffer of [record | partial] messages.
 template <typename T, int D>
 int run_tile_finish(const T* records, int64_t rstride, const double* partials, int64_t pstride, int64_t P,
                     int64_t rows_per_shard, int64_t N, double* out2, int* info, hipStream_t st) {
   using Cfg = TileCfg<T, D>;
-  if (P < 1 || P > (int64_t)Cfg::NT3 * Cfg::RCMAX) return -1;
-  const size_t lds3 = stage_lds_bytes<T, D>(Cfg::NT3);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NT3, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    attr_done = true;
-  }
-  const int rc = (int)((P + Cfg::NT3 - 1) / Cfg::NT3);
-  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st, records, P, rc,
-                     (T*)nullptr, (double*)nullptr, partials, P, out2, info, rows_per_shard, N, rstride, pstride);
+  if (P < 1 || P > (int64_t)Cfg::NTILE3 * Cfg::RCMAX) return -1;
+  const size_t lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
+  tile_set_attributes<T, D>();
+  const int rc = (int)((P + Cfg::NTILE3 - 1) / Cfg::NTILE3);
+  hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>), dim3(1), dim3(Cfg::NT3), lds3, st,
+                     records, P, rc, (T*)nullptr, (double*)nullptr, partials, P, out2, info, rows_per_shard, N,
+                     rstride, pstride);
   return 0;
 }
 

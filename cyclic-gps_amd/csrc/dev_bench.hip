@@ -12,6 +12,14 @@
 
 using namespace cgps;
 
+template <typename T, int D>
+__device__ __forceinline__ void set_identity(T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = (i == j) ? T(1) : T(0);
+}
+
 #define CK(x)                                                                      \
   do {                                                                             \
     hipError_t e_ = (x);                                                           \
@@ -115,42 +123,6 @@ __global__ __launch_bounds__(NT) void chunk_only_kernel(const T* __restrict__ Rg
   if (s == 123456.789 || fail) out[0] = s;
 }
 
-// ---- V3: LDS reduction only, with per-level clock stamps ----------------------------------
-template <typename T, int D, int NT>
-__global__ __launch_bounds__(NT) void tilecr_only_kernel(double* out, long long* stamps, int reps) {
-  constexpr int DD = D * D;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  LdsTile<T, D> t;
-  t.carve(smem, NT);
-  const int tid = threadIdx.x;
-  double mah = 0.0;
-  PivotLog pl;
-  bool fail = false;
-  for (int rep = 0; rep < reps; ++rep) {
-    T Rc[D][D], yc[D], Cc[D][D];
-    set_identity<T, D>(Rc);
-#pragma unroll
-    for (int i = 0; i < D; ++i) { Rc[i][i] = (T)2.5 + (T)0.001 * (T)tid; yc[i] = (T)0.1 * (T)(i + 1); }
-    set_zero<T, D>(Cc);
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) Cc[i][j] = (T)0.05 * (T)(i + 1) - (T)0.03 * (T)j;
-    LdsTile<T, D>::store_blk(t.R, tid, Rc);
-    store_vec<T, D>(t.y + tid * D, yc);
-    LdsTile<T, D>::store_blk(t.Oc, tid, Cc);
-    __syncthreads();
-    long long t0 = wall_clock64();
-    tile_cr<T, D, NT>(t, NT, pl, mah, fail);
-    long long t1 = wall_clock64();
-    if (tid == 0 && blockIdx.x == 0) stamps[rep] = t1 - t0;
-    __syncthreads();
-  }
-  double s = mah + pl.value();
-  if (s == 123456.789 || fail) out[0] = s;
-}
-
-
 // ---- probe: lane maps of v_mfma_f64_4x4x4_4b_f64 ------------------------------------------
 __global__ void mfma_probe_kernel(int* table) {
   const int lane = threadIdx.x;
@@ -240,26 +212,5 @@ int main(int argc, char** argv) {
   run_chunk_variants<T, D, 16, 64>(R, O, y, N, out, st, bytes);
   run_chunk_variants<T, D, 32, 64>(R, O, y, N, out, st, bytes);
 
-  {  // LDS reduction only
-    long long* stamps;
-    CK(hipMalloc(&stamps, 64 * sizeof(long long)));
-    auto run = [&](auto ntc, int grid) {
-      constexpr int NT = decltype(ntc)::value;
-      const size_t lds = stage_lds_bytes<T, D>(NT);
-      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tilecr_only_kernel<T, D, NT>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      float ms = time_ms([&] { hipLaunchKernelGGL((tilecr_only_kernel<T, D, NT>), dim3(grid), dim3(NT), lds, st, out, stamps, 4); }, 10, st);
-      long long h[4];
-      CK(hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost));
-      int levels = 0;
-      for (int s = 1; s < NT; s <<= 1) ++levels;
-      printf("tile_cr NT=%3d grid=%4d: kernel %7.2f us for 4 reps; in-kernel per rep (100MHz ticks -> us): %.2f %.2f %.2f %.2f  (%d levels => %.2f us/level)\n",
-             NT, grid, ms * 1e3, h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0, levels, h[3] / 100.0 / levels);
-    };
-    run(std::integral_constant<int, 256>{}, 1);
-    run(std::integral_constant<int, 256>{}, 512);
-    run(std::integral_constant<int, 512>{}, 1);
-    run(std::integral_constant<int, 64>{}, 1);
-  }
   return 0;
 }
