@@ -470,9 +470,25 @@ __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D
     store_vec<T, D>(t.y + tid * D, yc);
     LdsTile<T, D>::store_blk(t.Oc, tid, Cc);     // Oc[tid] = J[row tid, row tid-1]; Oc[0]: left of the tile
   }
+  // thread 0's share for the row left of the tile waits in LDS while the reduction runs, so it
+  // does not occupy registers across it
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) xch[i * D + j] = dRa[i][j];
+      xch[D * D + i] = dya[i];
+    }
+  }
   __syncthreads();
   const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
   if (rec_out != nullptr && tid == 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) dRa[i][j] = xch[i * D + j];
+      dya[i] = xch[D * D + i];
+    }
     collect_left_updates<T, D>(t, levels, dRa, dya);
     T Rs_[D][D], ys_[D], Cs_[D][D];
     LdsTile<T, D>::load_blk(t.R, n_real - 1, Rs_);
@@ -505,8 +521,14 @@ struct StageSmem {
 };
 
 // ---- stage 1 -----------------------------------------------------------------------------
+// (two workgroups per CU = two waves per SIMD: the streaming phase needs the second wave to
+// cover HBM latency when the grid is larger than the chip, so registers are capped at 256)
+// (blocks up to 4x4 fp64 / 5x5 fp32 fit that budget; larger ones get the whole register file)
+template <typename T, int D> constexpr int stage1_min_waves() {
+  return ((sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5)) ? 2 : 1;
+}
 template <typename T, int D, int C, int NT>
-__global__ __launch_bounds__(NT) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
+__global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
                                                           const T* __restrict__ Oleft,
                                                           T* __restrict__ rec, double* __restrict__ partial) {
@@ -689,7 +711,10 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __rest
 
 // ---- host side ------------------------------------------------------------------------------
 template <typename T, int D> constexpr bool tile_supported() {
-  return (sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5);
+  // every (dtype, d) whose 256-row tile fits the 160 KB of LDS: fp64 d <= 5, fp32 d <= 8.
+  // (Above fp64 d=4 / fp32 d=5 the one-lane-per-row code spills registers; it still reads the
+  // inputs once instead of three times, which is what counts for an HBM-bound path.)
+  return ((size_t)256 * (2 * D * D + D) + D * D) * sizeof(T) + 4096 <= 160 * 1024;
 }
 template <typename T, int D> struct TileCfg {
   static constexpr int C = 16;         // rows per lane in stage 1

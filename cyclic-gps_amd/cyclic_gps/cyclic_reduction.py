@@ -82,6 +82,7 @@ class CRDecomp(tuple):
         self = super().__new__(cls, (ms, Ds, Fs, Gs))
         self.packed = packed      # (Dp, Fp, Gp) on the GPU, or None
         self.like = like          # tensor whose device the results should follow
+        self.inputs = None        # (Rs, Os) when they require grad (set by decompose)
         return self
 
 
@@ -133,8 +134,23 @@ def decompose_step(Rs, Os):
     return (n, b(D), b(F), b(G)), (b(Rn), b(On))
 
 
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def decompose(Rs, Os):
-    """Full cyclic-reduction factorisation -> (ms, Ds, Fs, Gs)   (reference :287-309)."""
+    """Full cyclic-reduction factorisation -> (ms, Ds, Fs, Gs)   (reference :287-309).
+
+    The factor tensors themselves are plain (non-differentiable) device buffers; when Rs / Os
+    require grad the returned decomp remembers them, and det(decomp) / solve(decomp, y) /
+    mahal(decomp, y) differentiate with respect to them analytically (see _DetFn, _SolveFn)."""
+    dec = _decompose_raw(Rs.detach(), Os.detach())
+    if _needs_grad(Rs, Os):
+        dec.inputs = (Rs, Os)
+    return dec
+
+
+def _decompose_raw(Rs, Os):
     _check_blocks(Rs, Os)
     N, d = Rs.shape[0], Rs.shape[1]
     R, O = _stage(Rs), _stage(Os)
@@ -155,8 +171,76 @@ def decompose(Rs, Os):
 
 
 def mahal_and_det(Rs, Os, x):
-    """(x^T J^-1 x, log|J|) in one fused sweep, factor not kept   (reference :380-438)."""
+    """(x^T J^-1 x, log|J|) in one fused sweep, factor not kept   (reference :380-438).
+    Differentiable in Rs, Os and x (the reference trains through it, models.py:367-381)."""
+    if _needs_grad(Rs, Os, x):
+        return _MahalLogdetFn.apply(Rs, Os, x)
     return _mahal_and_det(Rs, Os, x, levelwise=False)
+
+
+# ----------------------------------------------------------------------------
+# analytic adjoints (SURVEY.md 7.5; checked against the reference's autograd in
+# tests/test_oracle.py::test_oracle_gradients_match_reference_autograd).  With w = J^-1 x and
+# Sig = J^-1:   m = x^T J^-1 x : dm/dx = 2w, dm/dR_i = -w_i w_i^T, dm/dO_i = -2 w_{i+1} w_i^T
+#               l = log|J|     : dl/dR_i = Sig_ii, dl/dO_i = 2 Sig_{i+1,i}
+#               s = u^T J^-1 y : with a = J^-1 u: ds/dy = a, ds/dR_i = -sym(a_i w_i^T),
+#                                ds/dO_i = -(a_{i+1} w_i^T + w_{i+1} a_i^T)
+# Every backward is solves and selected-inverse blocks on the same HIP kernels.
+# ----------------------------------------------------------------------------
+def _outer(a, b):
+    return a.unsqueeze(-1) * b.unsqueeze(-2)
+
+
+class _MahalLogdetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Rs, Os, x):
+        ctx.save_for_backward(Rs, Os, x)
+        return _mahal_and_det(Rs.detach(), Os.detach(), x.detach(), levelwise=False)
+
+    @staticmethod
+    def backward(ctx, gm, gl):
+        Rs, Os, x = ctx.saved_tensors
+        dec = _decompose_raw(Rs, Os)
+        w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
+        gR = -gm * _outer(w, w)
+        gO = -2 * gm * _outer(w[1:], w[:-1])
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            Sd, So = inverse_blocks(dec)
+            gR = gR + gl * Sd
+            gO = gO + 2 * gl * So
+        return gR, gO, (2 * gm * w).reshape(x.shape)
+
+
+class _DetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Rs, Os, dec):
+        ctx.dec = dec
+        return _det_raw(dec)
+
+    @staticmethod
+    def backward(ctx, g):
+        Sd, So = inverse_blocks(ctx.dec)
+        return g * Sd, 2 * g * So, None
+
+
+class _SolveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Rs, Os, y, dec):
+        w = _solve_raw(dec, y.detach())
+        ctx.dec = dec
+        ctx.save_for_backward(w)
+        return w
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        a = _solve_raw(ctx.dec, g.contiguous())
+        gR = gO = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            aw = _outer(a, w)
+            gR = -0.5 * (aw + aw.transpose(-1, -2))
+            gO = -(_outer(a[1:], w[:-1]) + _outer(w[1:], a[:-1]))
+        return gR, gO, a, None
 
 
 def _mahal_and_det(Rs, Os, x, levelwise):
@@ -215,8 +299,23 @@ def backhalfsolve(decomp, ycrr):
     return _back(x, src)
 
 
+def _decomp_inputs(decomp):
+    inp = getattr(decomp, "inputs", None)
+    return inp if inp is not None else (None, None)
+
+
 def solve(decomp, y):
-    """J^-1 y   (reference :441-444)."""
+    """J^-1 y   (reference :441-444).  Differentiable in y and in the Rs / Os the factor came from."""
+    Rs, Os = _decomp_inputs(decomp)
+    if _needs_grad(Rs, Os, y):
+        if Rs is None:       # only y carries grad: J^-1 is a constant symmetric operator
+            like = _packed(decomp)[5]
+            Rs = Os = torch.zeros(0, dtype=like.dtype, device=like.device)
+        return _SolveFn.apply(Rs, Os, y, decomp)
+    return _solve_raw(decomp, y)
+
+
+def _solve_raw(decomp, y):
     Dp, Fp, Gp, N, d, like = _packed(decomp)
     dev, dt = Dp.device, Dp.dtype
     v = _stage(y, dt).reshape(N, d)
@@ -229,7 +328,15 @@ def solve(decomp, y):
 
 
 def det(decomp):
-    """log|J| from the factor (the reference's name; it is the log-determinant)   (reference :447-458)."""
+    """log|J| from the factor (the reference's name; it is the log-determinant)   (reference :447-458).
+    Differentiable in the Rs / Os the factor came from."""
+    Rs, Os = _decomp_inputs(decomp)
+    if _needs_grad(Rs, Os):
+        return _DetFn.apply(Rs, Os, decomp)
+    return _det_raw(decomp)
+
+
+def _det_raw(decomp):
     Dp, Fp, Gp, N, d, like = _packed(decomp)
     dev, dt = Dp.device, Dp.dtype
     out = torch.empty(1, dtype=torch.float64, device=dev)

@@ -1,0 +1,143 @@
+"""Thin harness for BASELINE config 5: LEG marginal likelihood + in-sample posterior mean.
+
+This is NOT a re-implementation of the reference's `LEGFamily` (models.py is out of scope,
+SURVEY.md section 2); it is the minimum of the caller's math needed to FEED the cyclic-reduction
+path with the operands the reference feeds it, restated in our own code:
+
+    G            = N N^T + R - R^T + 1e-5 I                       (models.py:152-159)
+    Sigma^-1     = PEG precision blocks from exp(-1/2 dt G)        (models.py:181-239)
+    K            = Sigma^-1 + blockdiag(B^T (LL^T)^-1 B)           (models.py:254-268)
+    v            = x (LL^T)^-1 B                                   (models.py:270-280)
+    log p(x)     = -1/2 (mahal + logdet)                           (models.py:301-372)
+    posterior    = solve(decompose(K), v), inverse_blocks(...)     (models.py:282-298)
+
+The d x d assembly (matrix exponentials, two small solves per time gap) is embarrassingly
+parallel batched device work done with torch ops; everything block-tridiagonal goes through
+cyclic_gps.cyclic_reduction, i.e. the HIP kernels.  Tensors follow the device of `ts`.
+"""
+import math
+import os
+
+import torch
+
+from . import cyclic_reduction as cr
+
+
+class LEGMatrices:
+    """The four model matrices as the reference registers them (models.py:135-178):
+    N [d,d] lower triangular, R [d,d] strictly lower (G uses R - R^T), B [obs,d],
+    Lambda [obs,obs] lower triangular with softplus already applied."""
+
+    def __init__(self, N, R, B, Lambda):
+        self.N, self.R, self.B, self.Lambda = N, R, B, Lambda
+
+    def to(self, device):
+        return LEGMatrices(*(t.to(device) for t in (self.N, self.R, self.B, self.Lambda)))
+
+    @property
+    def G(self):
+        d = self.N.shape[0]
+        return self.N @ self.N.T + self.R - self.R.T + 1e-5 * torch.eye(d, dtype=self.N.dtype, device=self.N.device)
+
+    @property
+    def LLT_inv(self):
+        """(Lambda Lambda^T + 1e-9 I)^-1, obs_dim x obs_dim, used through plain matrix products
+        (torch.linalg.solve's GPU backward faults on ROCm 7.0 for a 1x1 system with hundreds of
+        right-hand sides; the inverse's backward is matmul only)."""
+        return torch.linalg.inv(self.LLT)
+
+    @property
+    def LLT(self):
+        o = self.Lambda.shape[0]
+        return self.Lambda @ self.Lambda.T + 1e-9 * torch.eye(o, dtype=self.Lambda.dtype, device=self.Lambda.device)
+
+
+def peg_precision(ts, G):
+    """Diagonal and lower off-diagonal blocks of the PEG prior precision (models.py:181-239)."""
+    d = G.shape[0]
+    eye = torch.eye(d, dtype=G.dtype, device=G.device)
+    dt = ts[1:] - ts[:-1]
+    E = torch.matrix_exp(-0.5 * G.unsqueeze(0) * dt.reshape(-1, 1, 1))
+    Et = E.transpose(-1, -2)
+    a = torch.linalg.solve(eye - Et @ E, Et)          # (I - E^T E)^-1 E^T
+    b = torch.linalg.solve(eye - E @ Et, E)           # (I - E E^T)^-1 E
+    c1, c2 = E @ a, Et @ b
+    Rs = eye.repeat(ts.shape[0], 1, 1)
+    Rs[:-1] += c2
+    Rs[1:] += c1
+    return Rs.contiguous(), (-b).contiguous()
+
+
+def posterior_precision(m, ts):
+    Rs, Os = peg_precision(ts, m.G)
+    BtLB = m.B.T @ m.LLT_inv @ m.B
+    return Rs + BtLB.unsqueeze(0), Os
+
+
+def compute_v(m, xs):
+    return (xs @ m.LLT_inv @ m.B).contiguous()
+
+
+def log_likelihood(m, ts, xs):
+    """log p(xs | ts) of the LEG model (models.py:301-372)."""
+    LLT = m.LLT
+    Li = m.LLT_inv
+    xl = xs @ Li
+    llt_mahal = (xl * xs).sum()
+    llt_det = torch.logdet(2 * math.pi * LLT) * xs.shape[0]
+    v = (xl @ m.B).contiguous()
+    Rs, Os = peg_precision(ts, m.G)
+    _, sig_inv_det = cr.mahal_and_det(Rs, Os, torch.zeros_like(v))       # = det(decompose(Rs, Os)), fused
+    K_Rs = Rs + (m.B.T @ Li @ m.B).unsqueeze(0)
+    k_mahal, k_det = cr.mahal_and_det(Rs=K_Rs, Os=Os, x=v)
+    return -0.5 * ((llt_mahal - k_mahal) + (llt_det + k_det - sig_inv_det))
+
+
+def insample_posterior(m, ts, xs):
+    """Posterior mean [N,d] and (diag, lower off-diag) covariance blocks (models.py:282-298)."""
+    K_Rs, K_Os = posterior_precision(m, ts)
+    dec = cr.decompose(Rs=K_Rs, Os=K_Os)
+    mean = cr.solve(dec, compute_v(m, xs))
+    return mean, cr.inverse_blocks(dec)
+
+
+# ---- the config-5 workload -----------------------------------------------------------------
+def co2_like_series(rows=770, seed=0, dtype=torch.float64):
+    """Mauna-Loa-shaped monthly series (decimal date, ppm): quadratic trend + annual and
+    semi-annual cycles + small noise.  Stand-in for ../data/co2_mm_mlo.csv, which is not part of
+    the reference repo (co2_data_experiments.py:17)."""
+    g = torch.Generator().manual_seed(seed)
+    t = 1958.2 + torch.arange(rows, dtype=dtype) / 12.0
+    u = t - 1958.0
+    x = 315.0 + 0.8 * u + 0.012 * u * u + 2.9 * torch.sin(2 * math.pi * t) + 0.8 * torch.sin(4 * math.pi * t + 0.6)
+    x = x + 0.3 * torch.randn(rows, dtype=dtype, generator=g)
+    return t, x.unsqueeze(-1)
+
+
+def load_co2_csv(path, dtype=torch.float64):
+    """The real file, when a user has it: columns as in co2_data_experiments.py:17-19."""
+    import numpy as np
+    rows = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if not line or line.startswith("#") or line[0].isalpha():
+                continue
+            rows.append([float(tok) for tok in line.replace(",", " ").split()])
+    a = np.array(rows)
+    return torch.tensor(a[:, 2], dtype=dtype), torch.tensor(a[:, 3], dtype=dtype).unsqueeze(-1)
+
+
+def co2_workload(path=None, dtype=torch.float64):
+    """(all_ts, all_xs, train_ts, train_xs) standardised and masked as the reference does
+    (co2_data_experiments.py:21-30, dataset_process_utils.py:9-25)."""
+    if path is not None and os.path.exists(path):
+        t, x = load_co2_csv(path, dtype)
+    else:
+        t, x = co2_like_series(dtype=dtype)
+    ts = 12 * (t - t.min())
+    xs = x - x.mean()
+    xs = xs / xs.std()
+    train_ts = torch.cat([ts[:262], ts[502:-28]])
+    train_xs = torch.cat([xs[:262], xs[502:-28]])
+    return ts, xs, train_ts, train_xs
