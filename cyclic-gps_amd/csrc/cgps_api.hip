@@ -10,6 +10,8 @@
 #include "../../include/cgps.h"
 #include "cgps_level.h"
 #include "cgps_tile.h"
+#include "cgps_solve_tile.h"
+#include <cstdlib>
 
 namespace {
 
@@ -153,9 +155,143 @@ int run_levelwise(const T* Rs, const T* Os, const T* x, int64_t N, T* Dp, T* Fp,
   return check_launch("levelwise reduction");
 }
 
+// ---- fused (tiled) substitution sweeps: cgps_solve_tile.h ---------------------------------------
+struct SolvePasses {
+  int np;
+  int first[8];
+  cgps::PassLevels lv[8];
+  int64_t rows[8];
+};
+
+void make_passes(const Layout& L, SolvePasses& P) {
+  P.np = 0;
+  int lvl = 0;
+  while (lvl < L.nlevels) {
+    const int64_t rows = L.ms[lvl];
+    const int remaining = L.nlevels - lvl;
+    const int nl = (rows <= cgps::SOLVE_TS) ? remaining : cgps::SOLVE_LP;   // <= SOLVE_LP + 1
+    cgps::PassLevels& pl = P.lv[P.np];
+    pl.nlev = nl;
+    pl.endD = L.offD[lvl + nl];
+    pl.endF = L.offF[lvl + nl < L.nlevels ? lvl + nl : L.nlevels - 1];
+    pl.endG = L.offG[lvl + nl < L.nlevels ? lvl + nl : L.nlevels - 1];
+    for (int j = 0; j < cgps::SOLVE_MAXLEV; ++j) {
+      const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+      pl.offD[j] = L.offD[l]; pl.offF[j] = L.offF[l]; pl.offG[j] = L.offG[l];
+      pl.m[j] = lvl + j < L.nlevels ? L.ms[l] : 0;
+    }
+    P.first[P.np] = lvl;
+    P.rows[P.np] = rows;
+    ++P.np;
+    lvl += nl;
+  }
+}
+
+bool levelwise_solve_requested() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CGPS_LEVELWISE_SOLVE");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
+template <typename T, int D>
+void solve_tile_attributes() {
+  static bool done = false;
+  if (done) return;
+  const int lds = (int)cgps::solve_lds_bytes<T, D>();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_tile_kernel<T, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_kernel<T, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  done = true;
+}
+
+template <typename T, int D>
+int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                       size_t ws_bytes, double* mahal_out, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P);
+  solve_tile_attributes<T, D>();
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
+  const size_t lds = cgps::solve_lds_bytes<T, D>();
+  const T* y = y0;
+  const T* owed_in = nullptr;
+  int64_t n_owed = 0, pb = 0;
+  for (int p = 0; p < P.np; ++p) {
+    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    const bool more = (p + 1 < P.np);
+    T* yout = more ? bufs[p & 1] : nullptr;            // [g][D] surviving rows, then [g][D] owed vectors
+    T* owed_out = more ? bufs[p & 1] + g * D : nullptr;
+    hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                       P.lv[p], owed_in, n_owed, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+    pb += g;
+    y = yout;
+    owed_in = owed_out;
+    n_owed = g;
+  }
+  if (mahal_out) {
+    double* tmp = partial + 2 * pb;  // one spare slot was reserved
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, tmp);
+    hipMemcpyAsync(mahal_out, tmp, sizeof(double), hipMemcpyDeviceToDevice, st);
+  }
+  return check_launch("halfsolve (tiled)");
+}
+
+template <typename T, int D>
+int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                       size_t ws_bytes, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);
+  if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P);
+  solve_tile_attributes<T, D>();
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
+                reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};
+  const size_t lds = cgps::solve_lds_bytes<T, D>();
+  const T* xc = nullptr;
+  for (int p = P.np - 1; p >= 0; --p) {
+    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    T* X = (p == 0) ? x : bufs[p & 1];
+    hipLaunchKernelGGL((cgps::backsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                       P.lv[p], ycrr, xc, n, X);
+    xc = X;
+  }
+  return check_launch("backsolve (tiled)");
+}
+
+template <typename T, int D>
+int run_halfsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                            size_t ws_bytes, double* mahal_out, hipStream_t st);
+template <typename T, int D>
+int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                            size_t ws_bytes, hipStream_t st);
+
 template <typename T, int D>
 int run_halfsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws, size_t ws_bytes,
                   double* mahal_out, hipStream_t st) {
+  if (levelwise_solve_requested()) return run_halfsolve_levelwise<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
+  return run_halfsolve_tile<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
+}
+template <typename T, int D>
+int run_backsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  if (levelwise_solve_requested()) return run_backsolve_levelwise<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
+  return run_backsolve_tile<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
+}
+
+template <typename T, int D>
+int run_halfsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                            size_t ws_bytes, double* mahal_out, hipStream_t st) {
   LevelWs w = level_ws(N, D, sizeof(T), false, true);
   if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
   Layout L;
@@ -182,8 +318,8 @@ int run_halfsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0,
 }
 
 template <typename T, int D>
-int run_backsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws, size_t ws_bytes,
-                  hipStream_t st) {
+int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                            size_t ws_bytes, hipStream_t st) {
   LevelWs w = level_ws(N, D, sizeof(T), false, true);
   // both ping-pong buffers must hold a level-1 vector here
   const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);

@@ -1,0 +1,229 @@
+// Fused forward / backward substitution with a stored cyclic-reduction factor
+// (reference halfsolve cyclic_reduction.py:312-338, backhalfsolve :341-377, in the
+// reference's exact even/odd order and CRR layout).
+//
+// With the factor stored, a row costs one d x d triangular solve and two d x d mat-vecs, and the
+// only state that must be shared between rows is the right-hand side: 8 d bytes per row.  So a
+// workgroup keeps the vectors of a TS = 1024-row tile in LDS and walks LP = 10 reduction levels
+// over them, while the D / F / G blocks of each level stream from HBM exactly once (consecutive
+// lanes read consecutive blocks of the level's packed array).  N = 2^20 needs two launches per
+// sweep instead of 21.
+//
+// In-place indexing: row r of local level j lives in slot (r + 1) 2^j - 1 of the tile, i.e. every
+// row stays where it was at local level 0; eliminated rows' slots are reused for x.
+// Tile boundaries: a tile's last row is odd at every local level, so it only ever RECEIVES
+// updates; the one it gets from the next tile's first row at each level is applied when the next
+// pass loads the survivors (forward sweep), respectively comes from the coarser pass (backward
+// sweep: the x of the previous tile's last row).
+#pragma once
+#include "cgps_math.h"
+
+namespace cgps {
+
+constexpr int SOLVE_LP = 10;            // levels per pass
+constexpr int SOLVE_TS = 1 << SOLVE_LP; // rows per tile
+constexpr int SOLVE_NT = 512;           // threads per workgroup (= eliminations of a tile's level 0)
+constexpr int SOLVE_MAXLEV = SOLVE_LP + 1;
+template <typename T, int D> constexpr size_t solve_lds_bytes() {
+  return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double);
+}
+
+// offsets (in blocks) of the levels one pass covers, and their sizes
+struct PassLevels {
+  int64_t offD[SOLVE_MAXLEV], offF[SOLVE_MAXLEV], offG[SOLVE_MAXLEV], m[SOLVE_MAXLEV];
+  int nlev;       // levels this pass runs
+  int64_t endD, endF, endG;   // one past the last block of this pass's levels in Dp / Fp / Gp
+};
+
+// A single-tile (top) pass is a chain of ~2 nlev dependent phases; touching its small,
+// contiguous slice of the factor once up front turns every later load into an L2 hit.
+template <typename T>
+__device__ __forceinline__ void warm_l2(const T* p, int64_t elems) {
+  const char* c = reinterpret_cast<const char*>(p);
+  const int64_t bytes = elems * (int64_t)sizeof(T);
+  int acc = 0;
+  for (int64_t o = (int64_t)threadIdx.x * 128; o < bytes; o += (int64_t)blockDim.x * 128)
+    acc += *reinterpret_cast<const volatile int*>(c + o);
+  asm volatile("" ::"v"(acc));
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void lds_load_vec(const T* p, T (&v)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = p[i];
+}
+template <typename T, int D>
+__device__ __forceinline__ void lds_store_vec(T* p, const T (&v)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) p[i] = v[i];
+}
+
+// ---- forward sweep ---------------------------------------------------------------------------
+// y_in  : the n rows of this pass (level lv.first); for pass > 0 these are the previous pass's
+//         surviving rows, each still missing what the NEXT tile's first rows owe it: owed_in[t] =
+//         sum over that pass's levels j of G_j x_j for tile t's first row (n_owed entries);
+//         row i takes owed_in[i + 1].
+// xcrr  : output, CRR layout (Dp offsets).   y_out : this pass's surviving rows (one per full tile).
+// owed_out[tile] : what this tile's first rows owe the previous tile's surviving row.
+template <typename T, int D>
+__global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ owed_in, int64_t n_owed, const T* __restrict__ y_in, int64_t n, T* __restrict__ xcrr,
+    T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* ys = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
+  double* red = reinterpret_cast<double*>(solve_smem + (size_t)SOLVE_TS * D * sizeof(T));
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * SOLVE_TS;
+  const int n0 = (int)((n - row0) < SOLVE_TS ? (n - row0) : SOLVE_TS);
+  if (gridDim.x == 1) {
+    warm_l2(Dp + lv.offD[0] * DD, (lv.endD - lv.offD[0]) * DD);
+    warm_l2(Fp + lv.offF[0] * DD, (lv.endF - lv.offF[0]) * DD);
+    warm_l2(Gp + lv.offG[0] * DD, (lv.endG - lv.offG[0]) * DD);
+  }
+  // load (and complete) the tile's rows
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    load_vec<T, D>(y_in + (row0 + r) * D, v);
+    if (owed_in != nullptr && row0 + r + 1 < n_owed) {
+      T w[D];
+      load_vec<T, D>(owed_in + (row0 + r + 1) * D, w);
+#pragma unroll
+      for (int i = 0; i < D; ++i) v[i] -= w[i];
+    }
+    lds_store_vec<T, D>(ys + r * D, v);
+  }
+  __syncthreads();
+  double mah = 0.0, zero = 0.0;
+  int nj = n0;
+  T owed[D];                                             // lane 0: sum_j G_j x_j of the tile's first rows
+#pragma unroll
+  for (int i = 0; i < D; ++i) owed[i] = T(0);
+  for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
+    const int ne = (nj + 1) >> 1, no = nj >> 1;
+    const int64_t g0 = row0 >> (j + 1);
+    for (int k = tid; k < ne; k += SOLVE_NT) {           // x_k = D_k^-1 y_2k
+      T L[D][D], x[D];
+      Chol<T, D> c;
+      load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
+      chol_from_dense<T, D>(L, c);
+      T* slot = ys + (size_t)(((2 * k + 1) << j) - 1) * D;
+      lds_load_vec<T, D>(slot, x);
+      fwd_subst<T, D>(c, x);
+      lds_store_vec<T, D>(slot, x);
+      store_vec<T, D>(xcrr + (lv.offD[j] + g0 + k) * D, x);
+#pragma unroll
+      for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+      if (k == 0 && g0 >= 1) {                           // the previous tile's last row is this row's left neighbour
+        T G[D][D];
+        load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, G);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int m2 = 0; m2 < D; ++m2) owed[i] = __builtin_fma(G[i][m2], x[m2], owed[i]);
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < no; k += SOLVE_NT) {           // y'_k = y_2k+1 - F_k x_k - G_k x_k+1
+      T M[D][D], x[D], yo[D];
+      T* slot = ys + (size_t)(((2 * k + 2) << j) - 1) * D;
+      lds_load_vec<T, D>(slot, yo);
+      load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
+      lds_load_vec<T, D>(ys + (size_t)(((2 * k + 1) << j) - 1) * D, x);
+      gemv_sub<T, D>(yo, M, x);
+      if (2 * k + 2 < nj) {                              // right neighbour inside the tile
+        load_block<T, D>(Gp + (lv.offG[j] + g0 + k) * DD, M);
+        lds_load_vec<T, D>(ys + (size_t)(((2 * k + 3) << j) - 1) * D, x);
+        gemv_sub<T, D>(yo, M, x);
+      }
+      lds_store_vec<T, D>(slot, yo);
+    }
+    __syncthreads();
+    nj = no;
+  }
+  if (nj == 1 && y_out != nullptr && tid == 0) {         // the tile's surviving row (full tiles only)
+    T v[D];
+    lds_load_vec<T, D>(ys + (size_t)(SOLVE_TS - 1) * D, v);
+    store_vec<T, D>(y_out + (size_t)blockIdx.x * D, v);
+  }
+  if (owed_out != nullptr && tid == 0) store_vec<T, D>(owed_out + (size_t)blockIdx.x * D, owed);
+  block_sum2<SOLVE_NT>(mah, zero, red);
+  if (tid == 0 && partial != nullptr) {
+    partial[2 * (size_t)blockIdx.x] = mah;
+    partial[2 * (size_t)blockIdx.x + 1] = 0.0;
+  }
+}
+
+// ---- backward sweep --------------------------------------------------------------------------
+// b      : right-hand side in CRR layout.   x_coarse : solution of this pass's surviving rows (one
+//          per full tile; level first + LP, natural order), nullptr for the top pass.
+// x_out  : solution of this pass's rows (level lv.first, natural order).
+template <typename T, int D>
+__global__ __launch_bounds__(SOLVE_NT) void backsolve_tile_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ b, const T* __restrict__ x_coarse, int64_t n, T* __restrict__ x_out) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* xs = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * SOLVE_TS;
+  const int n0 = (int)((n - row0) < SOLVE_TS ? (n - row0) : SOLVE_TS);
+  if (gridDim.x == 1) {
+    warm_l2(Dp + lv.offD[0] * DD, (lv.endD - lv.offD[0]) * DD);
+    warm_l2(Fp + lv.offF[0] * DD, (lv.endF - lv.offF[0]) * DD);
+    warm_l2(Gp + lv.offG[0] * DD, (lv.endG - lv.offG[0]) * DD);
+    warm_l2(b + lv.offD[0] * D, (lv.endD - lv.offD[0]) * D);
+  }
+  T xleft[D];                                            // x of the previous tile's last row
+#pragma unroll
+  for (int i = 0; i < D; ++i) xleft[i] = T(0);
+  if (x_coarse != nullptr) {
+    if (blockIdx.x > 0) load_vec<T, D>(x_coarse + ((size_t)blockIdx.x - 1) * D, xleft);
+    if (tid == 0 && n0 == SOLVE_TS) {                    // own surviving row
+      T v[D];
+      load_vec<T, D>(x_coarse + (size_t)blockIdx.x * D, v);
+      lds_store_vec<T, D>(xs + (size_t)(SOLVE_TS - 1) * D, v);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = lv.nlev - 1; j >= 0; --j) {
+    const int nj = n0 >> j;                              // floor at every level
+    if (nj >= 1) {
+      const int ne = (nj + 1) >> 1;
+      const int64_t g0 = row0 >> (j + 1);
+      for (int k = tid; k < ne; k += SOLVE_NT) {
+        T r[D], M[D][D], xo[D];
+        load_vec<T, D>(b + (lv.offD[j] + g0 + k) * D, r);
+        if (2 * k + 1 < nj) {
+          load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
+          lds_load_vec<T, D>(xs + (size_t)(((2 * k + 2) << j) - 1) * D, xo);
+          gemvT_sub<T, D>(r, M, xo);
+        }
+        if (k >= 1) {
+          load_block<T, D>(Gp + (lv.offG[j] + g0 + k - 1) * DD, M);
+          lds_load_vec<T, D>(xs + (size_t)(((2 * k) << j) - 1) * D, xo);
+          gemvT_sub<T, D>(r, M, xo);
+        } else if (g0 >= 1) {                            // left neighbour = previous tile's last row
+          load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, M);
+          gemvT_sub<T, D>(r, M, xleft);
+        }
+        T L[D][D];
+        Chol<T, D> c;
+        load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
+        chol_from_dense<T, D>(L, c);
+        bwd_subst<T, D>(c, r);
+        lds_store_vec<T, D>(xs + (size_t)(((2 * k + 1) << j) - 1) * D, r);
+      }
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    lds_load_vec<T, D>(xs + (size_t)r * D, v);
+    store_vec<T, D>(x_out + (row0 + r) * D, v);
+  }
+}
+
+}  // namespace cgps
