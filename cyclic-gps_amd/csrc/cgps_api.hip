@@ -11,6 +11,7 @@
 #include "cgps_level.h"
 #include "cgps_tile.h"
 #include "cgps_solve_tile.h"
+#include "cgps_decomp_tile.h"
 #include <cstdlib>
 
 namespace {
@@ -361,6 +362,56 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   return check_launch("inverse_blocks");
 }
 
+// ---- fused (tiled) factorisation: cgps_decomp_tile.h ------------------------------------------
+template <typename T, int D>
+int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
+                       hipStream_t st) {
+  using RL = cgps::RecordLayout<T, D>;
+  LevelWs w = level_ws(N, D, sizeof(T), true, false);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  static bool attr_done = false;
+  const size_t lds = cgps::decomp_lds_bytes<T, D>();
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_tile_kernel<T, D, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_tile_kernel<T, D, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  (void)hipMemsetAsync(info, 0, sizeof(int), st);
+  T* recs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};   // records of a pass
+  const T* rin = nullptr;
+  int64_t n_rec = 0;
+  int lvl = 0, p = 0;
+  while (lvl < L.nlevels) {
+    const int64_t rows = L.ms[lvl];
+    const int remaining = L.nlevels - lvl;
+    const int nl = (rows <= cgps::DEC_TS) ? remaining : cgps::DEC_LP;     // <= DEC_LP + 1
+    cgps::DecompLevels dl;
+    dl.nlev = nl;
+    for (int j = 0; j < cgps::DEC_MAXLEV; ++j) {
+      const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+      dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+    }
+    const int64_t g = (rows + cgps::DEC_TS - 1) / cgps::DEC_TS;
+    T* rout = recs[p & 1];
+    if (p == 0)
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false>), dim3((unsigned)g), dim3(cgps::DEC_NT), lds, st, Rs, Os,
+                         rows, (int64_t)0, dl, lvl, Dp, Fp, Gp, rout, info);
+    else
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, true>), dim3((unsigned)g), dim3(cgps::DEC_NT), lds, st, rin,
+                         (const T*)nullptr, rows, n_rec, dl, lvl, Dp, Fp, Gp, rout, info);
+    rin = rout;
+    n_rec = g;
+    lvl += nl;
+    ++p;
+  }
+  (void)RL::STRIDE;
+  return check_launch("decompose (tiled)");
+}
+
 bool bad_common(int64_t N, int d) { return N < 1 || d < 1; }
 
 }  // namespace
@@ -539,6 +590,13 @@ int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, 
   return dispatch(dtype, d, [&](auto t, auto dc) {
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
+    // tiled form for blocks whose one-lane code stays in registers (up to 4x4 fp64 / 5x5 fp32);
+    // larger blocks spill there and are faster level by level
+    if constexpr (cgps::stage1_min_waves<T, D>() == 2) {
+      if (!levelwise_solve_requested())
+        return run_decompose_tile<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, ws_bytes,
+                                        info, (hipStream_t)stream);
+    }
     return run_levelwise<T, D>((const T*)Rs, (const T*)Os, nullptr, N, (T*)Dp, (T*)Fp, (T*)Gp, nullptr, (char*)ws,
                                ws_bytes, nullptr, info, (hipStream_t)stream);
   });
