@@ -148,14 +148,19 @@ def main():
     from cyclic_gps import _hip
     lib = _hip.lib()
 
-    if world > 1:
+    # CGPS_BENCH_FORCE_SHARDED=1 runs the sharded code path with a single rank (rehearsal on a 1-GPU box)
+    force_sharded = os.environ.get("CGPS_BENCH_FORCE_SHARDED") == "1"
+    sharded_mode = world > 1 or force_sharded
+    use_dist = world > 1 or (force_sharded and "RANK" in os.environ)
+    if sharded_mode:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
         from cyclic_gps import sharded
+        if use_dist:
+            dist.init_process_group("nccl", device_id=dev)
     n_total = rows * world
 
     # ---- synthetic system, resident in HBM ------------------------------------------------
-    if world == 1:
+    if not sharded_mode:
         Rs, Os, b, x_true, logdet_true = make_system(rows, d, dtype, dev)
         mahal_true = float((x_true.double() * b.double()).sum())
     else:
@@ -168,7 +173,7 @@ def main():
     fn = lib.cgps_mahal_logdet_levelwise if args.levelwise else lib.cgps_mahal_logdet
     dcode = _hip.dtype_code(dtype)
 
-    if world == 1:
+    if not sharded_mode:
         def step():
             _hip.check(fn(_hip.ptr(Rs), _hip.ptr(Os), _hip.ptr(b), rows, d, dcode, _hip.ptr(ws), ws_bytes,
                           _hip.ptr(out), _hip.ptr(info), sp))
@@ -180,7 +185,7 @@ def main():
             plan.run(out)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -195,7 +200,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -226,7 +231,7 @@ def main():
     assert rel_ld < tol and rel_m < tol * 10, ("result mismatch", rel_ld, rel_m)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     s = 8 if dtype == torch.float64 else 4
@@ -266,14 +271,14 @@ def main():
             line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json"
     except Exception:
         pass
-    if world == 1 and not args.no_extras:
+    if not sharded_mode and not args.no_extras:
         line["extras"] = extra_measurements(dev)
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and not sharded_mode:
         line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
