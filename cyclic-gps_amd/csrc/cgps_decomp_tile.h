@@ -122,7 +122,7 @@ __device__ __forceinline__ int tile_cr_factor(LdsTile<T, D>& t, int n0, bool kee
               for (int jj = 0; jj < D; ++jj) {
                 T sacc = T(0);
 #pragma unroll
-                for (int m = 0; m < D; ++m) sacc = __builtin_fma(-F[i][m], G[jj][m], sacc);
+                for (int m = 0; m < D; ++m) sacc = fmaT(-F[i][m], G[jj][m], sacc);
                 W[i][jj] = sacc;
               }
             }

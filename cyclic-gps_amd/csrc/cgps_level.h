@@ -223,7 +223,7 @@ __device__ __forceinline__ void mm(T (&C)[D][D], const T (&A)[D][D], const T (&B
     for (int j = 0; j < D; ++j) {
       T s = T(0);
 #pragma unroll
-      for (int m = 0; m < D; ++m) s = __builtin_fma(A[i][m], B[m][j], s);
+      for (int m = 0; m < D; ++m) s = fmaT(A[i][m], B[m][j], s);
       C[i][j] = s;
     }
 }
@@ -236,7 +236,7 @@ __device__ __forceinline__ void mm_tn_acc(T (&C)[D][D], const T (&A)[D][D], cons
     for (int j = 0; j < D; ++j) {
       T s = C[i][j];
 #pragma unroll
-      for (int m = 0; m < D; ++m) s = __builtin_fma(A[m][i], B[m][j], s);
+      for (int m = 0; m < D; ++m) s = fmaT(A[m][i], B[m][j], s);
       C[i][j] = s;
     }
 }
@@ -249,7 +249,7 @@ __device__ __forceinline__ void mm_acc(T (&C)[D][D], const T (&A)[D][D], const T
     for (int j = 0; j < D; ++j) {
       T s = C[i][j];
 #pragma unroll
-      for (int m = 0; m < D; ++m) s = __builtin_fma(A[i][m], B[m][j], s);
+      for (int m = 0; m < D; ++m) s = fmaT(A[i][m], B[m][j], s);
       C[i][j] = s;
     }
 }

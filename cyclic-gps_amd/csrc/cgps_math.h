@@ -16,6 +16,11 @@ template <typename T> struct Vec16;  // 16-byte vector of T for wide global/LDS 
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
 template <> struct Vec16<float>  { using type = float4;  static constexpr int N = 4; };
 
+// fused multiply-add in the block's own precision (__builtin_fma alone is the double one: with
+// float operands it converts, multiplies in fp64 and converts back)
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // ---- reciprocal square root -------------------------------------------------
 // v_rsq_f64 is good to ~2^-23 relative; two Newton steps bring it to ~1 ulp.
 __device__ __forceinline__ double rsqrt_fast(double s) {
@@ -50,7 +55,7 @@ __device__ __forceinline__ double chol_lower(const T (&A)[D][D], Chol<T, D>& c, 
   for (int j = 0; j < D; ++j) {
     T s = A[j][j];
 #pragma unroll
-    for (int m = 0; m < j; ++m) s = __builtin_fma(-c.l[j][m], c.l[j][m], s);
+    for (int m = 0; m < j; ++m) s = fmaT(-c.l[j][m], c.l[j][m], s);
     fail = fail || !(s > T(0));
     piv *= (double)s;
     T r = rsqrt_fast(s);
@@ -60,7 +65,7 @@ __device__ __forceinline__ double chol_lower(const T (&A)[D][D], Chol<T, D>& c, 
     for (int i = j + 1; i < D; ++i) {
       T t = A[i][j];
 #pragma unroll
-      for (int m = 0; m < j; ++m) t = __builtin_fma(-c.l[i][m], c.l[j][m], t);
+      for (int m = 0; m < j; ++m) t = fmaT(-c.l[i][m], c.l[j][m], t);
       c.l[i][j] = t * r;
     }
   }
@@ -75,7 +80,7 @@ __device__ __forceinline__ void fwd_subst(const Chol<T, D>& c, T (&v)[D]) {
   for (int j = 0; j < D; ++j) {
     T s = v[j];
 #pragma unroll
-    for (int m = 0; m < j; ++m) s = __builtin_fma(-c.l[j][m], v[m], s);
+    for (int m = 0; m < j; ++m) s = fmaT(-c.l[j][m], v[m], s);
     v[j] = s * c.inv[j];
   }
 }
@@ -87,7 +92,7 @@ __device__ __forceinline__ void bwd_subst(const Chol<T, D>& c, T (&v)[D]) {
   for (int j = D - 1; j >= 0; --j) {
     T s = v[j];
 #pragma unroll
-    for (int m = j + 1; m < D; ++m) s = __builtin_fma(-c.l[m][j], v[m], s);
+    for (int m = j + 1; m < D; ++m) s = fmaT(-c.l[m][j], v[m], s);
     v[j] = s * c.inv[j];
   }
 }
@@ -119,7 +124,7 @@ __device__ __forceinline__ void syrk_sub_lower(T (&S)[D][D], const T (&A)[D][D])
     for (int j = 0; j <= i; ++j) {
       T s = S[i][j];
 #pragma unroll
-      for (int m = 0; m < D; ++m) s = __builtin_fma(-A[i][m], A[j][m], s);
+      for (int m = 0; m < D; ++m) s = fmaT(-A[i][m], A[j][m], s);
       S[i][j] = s;
     }
 }
@@ -131,7 +136,7 @@ __device__ __forceinline__ void gemv_sub(T (&y)[D], const T (&A)[D][D], const T 
   for (int i = 0; i < D; ++i) {
     T s = y[i];
 #pragma unroll
-    for (int m = 0; m < D; ++m) s = __builtin_fma(-A[i][m], x[m], s);
+    for (int m = 0; m < D; ++m) s = fmaT(-A[i][m], x[m], s);
     y[i] = s;
   }
 }
@@ -143,7 +148,7 @@ __device__ __forceinline__ void gemvT_sub(T (&y)[D], const T (&A)[D][D], const T
   for (int i = 0; i < D; ++i) {
     T s = y[i];
 #pragma unroll
-    for (int m = 0; m < D; ++m) s = __builtin_fma(-A[m][i], x[m], s);
+    for (int m = 0; m < D; ++m) s = fmaT(-A[m][i], x[m], s);
     y[i] = s;
   }
 }
@@ -157,7 +162,7 @@ __device__ __forceinline__ void neg_abt(T (&C)[D][D], const T (&A)[D][D], const 
     for (int j = 0; j < D; ++j) {
       T s = T(0);
 #pragma unroll
-      for (int m = 0; m < D; ++m) s = __builtin_fma(-A[i][m], B[j][m], s);
+      for (int m = 0; m < D; ++m) s = fmaT(-A[i][m], B[j][m], s);
       C[i][j] = s;
     }
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-          for (int m2 = 0; m2 < D; ++m2) owed[i] = __builtin_fma(G[i][m2], x[m2], owed[i]);
+          for (int m2 = 0; m2 < D; ++m2) owed[i] = fmaT(G[i][m2], x[m2], owed[i]);
       }
     }
     __syncthreads();

@@ -152,7 +152,7 @@ __device__ __forceinline__ void syrk_lower(T (&S)[D][D], const T (&A)[D][D]) {
       T s = T(0);
       if (j <= i) {
 #pragma unroll
-        for (int m = 0; m < D; ++m) s = __builtin_fma(A[i][m], A[j][m], s);
+        for (int m = 0; m < D; ++m) s = fmaT(A[i][m], A[j][m], s);
       }
       S[i][j] = s;
     }
@@ -294,7 +294,7 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
 #pragma unroll
           for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int m = 0; m < D; ++m) wv[i] = __builtin_fma(G[i][m], x[m], wv[i]);
+            for (int m = 0; m < D; ++m) wv[i] = fmaT(G[i][m], x[m], wv[i]);
         } else if (role == 1) {
           T F[D][D];
           LT::load_blk(t.Oc, e + 1, F);
@@ -329,7 +329,7 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
               for (int j = 0; j < D; ++j) {
                 T sacc = T(0);
 #pragma unroll
-                for (int m = 0; m < D; ++m) sacc = __builtin_fma(-F[i][m], G[j][m], sacc);
+                for (int m = 0; m < D; ++m) sacc = fmaT(-F[i][m], G[j][m], sacc);
                 W[i][j] = sacc;
               }
             }
@@ -709,6 +709,9 @@ __global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __rest
   }
 }
 
+// ---- stage 1 for large blocks: one block row over four lanes --------------------------------------
+#include "cgps_tile_ml.h"
+
 // ---- host side ------------------------------------------------------------------------------
 template <typename T, int D> constexpr bool tile_supported() {
   // every (dtype, d) whose 256-row tile fits the 160 KB of LDS: fp64 d <= 5, fp32 d <= 8.
@@ -722,11 +725,16 @@ template <typename T, int D> struct TileCfg {
   static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
   static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
   static constexpr int RCMAX = 4;      // records a stage-3 lane eliminates sequentially before the LDS reduction
+  // lanes sharing one block row in stage 1 (cgps_tile_ml.h): 8 x 8 blocks do not fit one lane's registers
+  static constexpr int LPR = (D == 8) ? 4 : 1;
+  static constexpr int NG1 = NT1 / LPR;                 // kept rows (= LDS tile slots) per stage-1 workgroup
+  static constexpr int64_t ROWS1 = (int64_t)C * NG1;    // rows per stage-1 workgroup
 };
-constexpr int64_t TILE_ROWS_MIN = 16 * 256;   // smallest rows-per-tile over all TileCfg (workspace sizing)
+// TileCfg<T, d>::ROWS1 for a run-time d (workspace sizing)
+inline int64_t tile_rows1(int d) { return d == 8 ? 16 * 256 / 4 : 16 * 256; }
 
 inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
-  const int64_t tiles = N / TILE_ROWS_MIN + 2;
+  const int64_t tiles = N / tile_rows1(d) + 2;
   const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
   const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
@@ -737,9 +745,13 @@ void tile_set_attributes() {
   using Cfg = TileCfg<T, D>;
   static bool done = false;
   if (done) return;
-  const int lds1 = (int)stage_lds_bytes<T, D>(Cfg::NT1, Cfg::NT1), lds3 = (int)stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  const int lds1 = (int)stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = (int)stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
+  if constexpr (Cfg::LPR > 1)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  else
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
@@ -759,18 +771,22 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   using Cfg = TileCfg<T, D>;
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
-  const int64_t rows_per_tile = (int64_t)Cfg::C * Cfg::NT1;
+  const int64_t rows_per_tile = Cfg::ROWS1;
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
-  const int64_t tiles_cap = N / TILE_ROWS_MIN + 2;
+  const int64_t tiles_cap = N / tile_rows1(D) + 2;
   double* partial = reinterpret_cast<double*>(ws);
   const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   T* recA = reinterpret_cast<T*>(ws + pbytes);
   T* recB = recA + (size_t)(tiles_cap + 2) * RL::STRIDE;
-  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NT1, Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
+  const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
   tile_set_attributes<T, D>();
   if (ev_start) (void)hipEventRecord(ev_start, st);
-  hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                     Rs, Os, x, N, Oleft, recA, partial);
+  if constexpr (Cfg::LPR > 1)
+    hipLaunchKernelGGL((chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>), dim3((unsigned)tiles), dim3(Cfg::NT1),
+                       lds1, st, Rs, Os, x, N, Oleft, recA, partial);
+  else
+    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                       Rs, Os, x, N, Oleft, recA, partial);
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;
   T *rin = recA, *rout = recB;
