@@ -720,7 +720,7 @@ template <typename T, int D> constexpr bool tile_supported() {
   return ((size_t)256 * (2 * D * D + D) + D * D) * sizeof(T) + 4096 <= 160 * 1024;
 }
 template <typename T, int D> struct TileCfg {
-  static constexpr int C = 16;         // rows per lane in stage 1
+  static constexpr int C = (D == 8) ? 64 : 16;   // rows per lane (per lane group) in stage 1
   static constexpr int NT1 = 256;      // lanes (= threads) per workgroup in stage 1
   static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
   static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
@@ -731,7 +731,7 @@ template <typename T, int D> struct TileCfg {
   static constexpr int64_t ROWS1 = (int64_t)C * NG1;    // rows per stage-1 workgroup
 };
 // TileCfg<T, d>::ROWS1 for a run-time d (workspace sizing)
-inline int64_t tile_rows1(int d) { return d == 8 ? 16 * 256 / 4 : 16 * 256; }
+inline int64_t tile_rows1(int d) { return d == 8 ? 64 * 256 / 4 : 16 * 256; }
 
 inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
   const int64_t tiles = N / tile_rows1(d) + 2;
@@ -772,6 +772,7 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
   const int64_t rows_per_tile = Cfg::ROWS1;
+  if (rows_per_tile != tile_rows1(D)) return -1;        // the two definitions of ROWS1 must agree
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
   const int64_t tiles_cap = N / tile_rows1(D) + 2;
   double* partial = reinterpret_cast<double*>(ws);

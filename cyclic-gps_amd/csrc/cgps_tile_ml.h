@@ -22,9 +22,24 @@ struct MlGroup {
   static constexpr int RP = D / LPR;
   static_assert(D % LPR == 0 && (LPR & (LPR - 1)) == 0, "block size must split evenly over a power-of-two group");
   // value of `v` held by lane `src_q` of this lane's group
+  // (src_q is a compile-time constant at every call site once the loops are unrolled.  A group of
+  // four lanes is a DPP quad: quad_perm broadcasts inside it on the VALU, no LDS round trip.)
+  template <int Q>
+  static __device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xf, 0xf, true));
+  }
   static __device__ __forceinline__ T from(T v, int src_q) {
-    const int lane = threadIdx.x & 63;
-    return __shfl(v, (lane & ~(LPR - 1)) | src_q, 64);
+    if constexpr (LPR == 4 && sizeof(T) == 4) {
+      switch (src_q) {
+        case 0: return quad_bcast<0>(v);
+        case 1: return quad_bcast<1>(v);
+        case 2: return quad_bcast<2>(v);
+        default: return quad_bcast<3>(v);
+      }
+    } else {
+      const int lane = threadIdx.x & 63;
+      return __shfl(v, (lane & ~(LPR - 1)) | src_q, 64);
+    }
   }
   // all D rows of a row-sliced matrix: full[i][j] = own[i % RP][j] of lane i / RP
   static __device__ __forceinline__ void gather(const T (&own)[RP][D], T (&full)[D][D]) {

@@ -81,8 +81,10 @@ def test_ragged_sizes_against_oracle(d, dtype):
     """Every N from 1 to 70 plus sizes around the tile widths: even/odd counts at every level."""
     tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-4)
     sizes = list(range(1, 71)) + [127, 128, 129, 255, 256, 257, 511, 513, 1000, 1023, 1025, 2049, 4097, 5000]
-    if d in (1, 4, 5):      # tile-boundary cases of the multi-pass kernels: one-row ragged tiles at two passes
-        sizes += [65537, 66049, 131073]
+    if d in (1, 4, 5, 8):   # tile-boundary cases of the multi-pass kernels: one-row ragged tiles at two passes
+        sizes += [65537, 66049, 131073]   # (d = 8: the four-lanes-per-row streaming kernel, 4096-row tiles)
+    if d == 8:
+        sizes += [4095, 4096, 8191, 8193, 12289]
     for n in sizes:
         Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, seed=100 + n)
         ref_m, ref_ld = O.mahal_and_det(Rs, Os, b)
