@@ -531,7 +531,7 @@ int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void*
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
     if constexpr (!cgps::tile_supported<T, D>()) {
-      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=4 and fp32 d<=5");
+      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=5 and fp32 d<=8");
     } else {
       int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, n_loc, (char*)ws, ws_bytes,
                                                  nullptr, nullptr, (hipStream_t)stream, g_prof_start, g_prof_stop,
@@ -552,7 +552,7 @@ int cgps_finish_records(const void* records, size_t record_stride_bytes, const d
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
     if constexpr (!cgps::tile_supported<T, D>()) {
-      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=4 and fp32 d<=5");
+      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=5 and fp32 d<=8");
     } else {
       if (record_stride_bytes % sizeof(T) != 0 || partial_stride_bytes % sizeof(double) != 0 ||
           record_stride_bytes < cgps::RecordLayout<T, D>::STRIDE * sizeof(T) || partial_stride_bytes < 32)
