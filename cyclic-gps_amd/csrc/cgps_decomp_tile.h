@@ -19,8 +19,8 @@
 
 namespace cgps {
 
-constexpr int DEC_LP = 8;
-constexpr int DEC_TS = 1 << DEC_LP;     // 256 rows per tile
+constexpr int DEC_LP = 7;
+constexpr int DEC_TS = 1 << DEC_LP;     // rows per tile
 constexpr int DEC_NT = 256;             // four waves
 constexpr int DEC_MAXLEV = DEC_LP + 1;
 
