@@ -371,40 +371,53 @@ int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp,
   if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
   Layout L;
   make_layout(N, L);
-  static bool attr_done = false;
-  const size_t lds = cgps::decomp_lds_bytes<T, D>();
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_tile_kernel<T, D, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_tile_kernel<T, D, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  // persistent waves: as many workgroups (one wave each) as the chip holds at once
+  const size_t lds = (size_t)64 * D * D * sizeof(T);      // staging of the coalesced factor stores
+  static int grid_cap[2] = {0, 0};
+  if (grid_cap[0] == 0) {
+    int dev = 0, cus = 256, nb0 = 4, nb1 = 4;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, cgps::decomp_tile_kernel<T, D, false>, cgps::DEC_NT, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, cgps::decomp_tile_kernel<T, D, true>, cgps::DEC_NT, lds);
+    grid_cap[0] = cus * (nb0 > 0 ? nb0 : 1);
+    grid_cap[1] = cus * (nb1 > 0 ? nb1 : 1);
   }
   (void)hipMemsetAsync(info, 0, sizeof(int), st);
   T* recs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};   // records of a pass
   const T* rin = nullptr;
   int64_t n_rec = 0;
-  int lvl = 0, p = 0;
+  int lvl = 0, p = 0, spt_in = 1;
   while (lvl < L.nlevels) {
     const int64_t rows = L.ms[lvl];
     const int remaining = L.nlevels - lvl;
-    const int nl = (rows <= cgps::DEC_TS) ? remaining : cgps::DEC_LP;     // <= DEC_LP + 1
+    const int64_t g = (rows + cgps::DEC_TS - 1) / cgps::DEC_TS;
+    const bool top = g == 1;                                               // one tile takes it to the end
+    // many tiles: a few levels per pass keep the lanes busy; few tiles: all levels of a tile
+    const int nl = top ? remaining : (g >= cgps::DEC_FEW_TILES ? cgps::DEC_LP : cgps::DEC_TS_LOG2);   // <= DEC_MAXLEV
     cgps::DecompLevels dl;
     dl.nlev = nl;
     for (int j = 0; j < cgps::DEC_MAXLEV; ++j) {
       const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
       dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
     }
-    const int64_t g = (rows + cgps::DEC_TS - 1) / cgps::DEC_TS;
-    T* rout = recs[p & 1];
+    T* rout = top ? nullptr : recs[p & 1];
+    const int64_t cap = grid_cap[p == 0 ? 0 : 1];
+    const unsigned grid = (unsigned)(g < cap ? g : cap);
     if (p == 0)
-      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false>), dim3((unsigned)g), dim3(cgps::DEC_NT), lds, st, Rs, Os,
-                         rows, (int64_t)0, dl, lvl, Dp, Fp, Gp, rout, info);
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false>), dim3(grid), dim3(cgps::DEC_NT), lds, st, Rs, Os,
+                         rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
     else
-      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, true>), dim3((unsigned)g), dim3(cgps::DEC_NT), lds, st, rin,
-                         (const T*)nullptr, rows, n_rec, dl, lvl, Dp, Fp, Gp, rout, info);
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, true>), dim3(grid), dim3(cgps::DEC_NT), lds, st, rin,
+                         (const T*)nullptr, rows, n_rec, spt_in, dl, lvl, Dp, Fp, Gp, rout, info);
     rin = rout;
-    n_rec = g;
+    // every tile leaves DEC_TS >> nl records, the last one what survives of it, at least one
+    {
+      const int64_t spt = cgps::DEC_TS >> nl;
+      const int64_t last = (rows - (g - 1) * cgps::DEC_TS) >> nl;
+      n_rec = (g - 1) * spt + (last > 0 ? last : 1);
+      spt_in = (int)(spt > 0 ? spt : 1);
+    }
     lvl += nl;
     ++p;
   }

@@ -1,156 +1,134 @@
 // Fused factor-emitting cyclic reduction (decompose, reference cyclic_reduction.py:287-309):
 // the reference's exact even/odd elimination order, so the emitted Ds / Fs / Gs are the
-// reference's blocks, but LP = 8 levels per launch instead of one.
+// reference's blocks, but several levels per launch instead of one.
 //
-// A workgroup holds a TS = 256-row tile (R and the couplings) in LDS and runs the role-split
-// reduction of cgps_tile.h on it (four waves share one elimination: left products / right
-// update / two halves of the new coupling), except that
-//   * it starts at level 0 of the pass (no streaming stage: the order is prescribed),
-//   * role 0 also writes D (dense lower factor) and G, role 1 writes F, straight into the
-//     packed per-level arrays (index = global elimination index of that level),
-//   * the LAST tile follows the reference's size rule (its last row IS eliminated when it is
-//     even, cyclic_reduction.py:240-248); every other tile is full and keeps its last row as
-//     the boundary, leaving a record (row, coupling to the previous tile's row, update owed to
-//     it) that the next pass assembles into the level-(8p+8) system.
-// N = 2^20 needs three launches (2^20 -> 4096 -> 16 -> done) instead of 21, and reads every
-// input block once.
+// ONE WAVE per 128-row tile, the tile in REGISTERS, no LDS: lane k loads rows 2k and 2k+1, and a
+// level's neighbour exchange (what an eliminated row owes the odd rows left and right of it, and
+// the new coupling between those two) goes through wave shuffles.  Why:
+//   * this kernel runs in the throughput regime (thousands of tiles); with the tile in LDS
+//     (256 B per row) only ~640 rows fit a CU, one wave per SIMD, and every latency of a level
+//     (LDS round trips, the dependent fp64 chain, the global stores) was exposed: 182-218 us for
+//     the first pass at N = 2^20;
+//   * waves are persistent (grid = what the chip holds); the factor blocks go out through a small
+//     LDS staging buffer so that every store instruction writes whole 128-byte lines;
+//   * a level with fewer eliminations than lanes wastes the idle lanes, so a pass over many
+//     tiles stops after DEC_LP = 3 levels (64 + 32 + 16 eliminations on 64 lanes) and hands the
+//     16 surviving rows of every tile to the next pass as records; a pass over few tiles is
+//     latency-bound anyway and runs all 7 levels of its tiles (one survivor each).
+// Level j >= 1 of a pass: its rows m sit in lanes (m+1) st - 1, st = 2^(j-1); lane e of an even
+// row takes the coupling J[m+1, m] from lane e + st, computes D, G, F (written straight into the
+// packed per-level arrays; index = global elimination index of that level) and sends G G^T to
+// lane e - st, F F^T and the new coupling -F G^T to lane e + st.
+//   * the reference's size rule decides what a level eliminates (the last row too when its index
+//     is even, cyclic_reduction.py:240-248); tiles start at multiples of 128, so local and global
+//     parities agree at every level of a pass;
+//   * what a tile's first eliminations owe the previous tile's last row travels as the DRA part
+//     of the tile's first record and is added when the next pass loads that row.
+// N = 2^20: five launches (2^20 -> 2^17 -> 2^14 -> 2^7 -> done), every input block read once,
+// survivors written and re-read once per pass.
 #pragma once
 #include "cgps_tile.h"
 
 namespace cgps {
 
-constexpr int DEC_LP = 7;
-constexpr int DEC_TS = 1 << DEC_LP;     // rows per tile
-constexpr int DEC_NT = 256;             // four waves
-constexpr int DEC_MAXLEV = DEC_LP + 1;
+constexpr int DEC_LP = 3;               // levels per pass over many tiles
+constexpr int DEC_TS = 128;             // rows per tile: two per lane
+constexpr int DEC_TS_LOG2 = 7;          // levels per pass over few tiles (one survivor per tile)
+constexpr int DEC_NT = 64;              // one wave
+constexpr int DEC_MAXLEV = 8;           // the last pass takes a system of <= DEC_TS rows to the end: log2(128) + 1
+constexpr int64_t DEC_FEW_TILES = 512;  // below this a pass is latency-bound: run all levels of a tile
 
 struct DecompLevels {
   int64_t offD[DEC_MAXLEV], offF[DEC_MAXLEV], offG[DEC_MAXLEV];
   int nlev;
 };
 
+// a block / the lower triangle of a symmetric block as held by lane `src` (every lane of the wave
+// executes this; lanes whose src is out of range get something they must not use)
 template <typename T, int D>
-constexpr size_t decomp_lds_bytes() {
-  return (((size_t)DEC_TS * 2 * D * D + D * D) * sizeof(T) + 15 & ~(size_t)15) + 256;
+__device__ __forceinline__ void shfl_block(T (&dst)[D][D], const T (&v)[D][D], int src) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) dst[a][b] = __shfl(v[a][b], src, 64);
+}
+template <typename T, int D>
+__device__ __forceinline__ void shfl_lower(T (&dst)[D][D], const T (&v)[D][D], int src) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) dst[a][b] = __shfl(v[a][b], src, 64);
+}
+template <typename T, int D>
+__device__ __forceinline__ void sub_lower(T (&S)[D][D], const T (&U)[D][D]) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) S[a][b] -= U[a][b];
 }
 
-// Reduction of the n0-row tile with factor emission.  keep_last: the tile's last row is a
-// boundary (never eliminated).  row0 = index of the tile's first row at the pass's first level.
-// Returns the number of executed levels.  LDS: R[TS][DD], Oc[TS+1][DD] (as LdsTile, y unused).
+// The blocks of a wave's eliminations k = 0 .. cnt-1 (lane holds block k if `has`) -> the
+// contiguous array dst[cnt][D*D], through LDS so that every store instruction writes 64 x 16
+// consecutive bytes.  Stored straight from the lanes, each instruction would touch 64 different
+// 128-byte lines 16 bytes at a time: the write path then runs at a fraction of its rate (first
+// pass at N = 2^20: 170 us with such stores, 79 us with none).  `first` skips leading blocks
+// (G of the system's very first row does not exist).  `stage` holds 64 blocks.
+// ONE wave only: a wave's LDS instructions execute in issue order, so the write and the read
+// phase need no barrier, just the compiler kept from reordering them -- a __syncthreads() here
+// would also wait for every global store and prefetch load in flight (vmcnt(0)), which is what
+// made the earlier versions of this kernel slow.
 template <typename T, int D>
-__device__ __forceinline__ int tile_cr_factor(LdsTile<T, D>& t, int n0, bool keep_last, int64_t row0,
-                                              const DecompLevels& lv, T* __restrict__ Dp, T* __restrict__ Fp,
-                                              T* __restrict__ Gp, int lvl_first, int* info, bool& fail) {
-  using LT = LdsTile<T, D>;
-  constexpr int DD = D * D;
-  constexpr int DH = (D + 1) / 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int role = wave & 3;
-  const int K = n0 - 1;
-  const int kl = keep_last ? 1 : 0;
-  int levels = 0;
-#pragma unroll 1
-  for (int s = 1, j = 0; j < lv.nlev && (keep_last ? (s - 1) < K : (n0 >> j) >= 1); s <<= 1, ++j, ++levels) {
-    const int M = n0 >> j, h = s >> 1;
-    const int n_elim = (M + 1) / 2;
-    const int64_t g0 = row0 >> (j + 1);
-#pragma unroll 1
-    for (int k0 = 0; k0 < n_elim; k0 += 64) {
-      const int k = k0 + lane;
-      const int e = (2 * k + 1) * s - 1;
-      const bool act = (2 * k < M) && (e != K || !keep_last);
-      const bool has_o = act && ((2 * k + 1 < M) || (keep_last && e < K));
-      const int o = (2 * k + 1 < M) ? e + s : K;
-      const int64_t ge = g0 + k;
-      T W[D][D];
-      if (act) {
-        T A[D][D];
-        LT::load_blk(t.R, e, A);
-        if ((s > 1) && (e + h < K + 1 - kl)) {
-          T P[D][D];
-          LT::load_blk(t.R, e + h, P);
+__device__ __forceinline__ void store_blocks_coalesced(T* stage, T* __restrict__ dst, const T (&A)[D][D], bool has, int k,
+                                                       int cnt, int first) {
+  constexpr int DD = D * D, VN = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  if constexpr (DD % VN == 0) {
+    using V = typename Vec16<T>::type;
+    constexpr int G = DD / VN;                                    // 16-byte granules per block
+    constexpr bool SWZ = (G & (G - 1)) == 0 && G >= 2;            // spread a column of granules over the banks
+    V* sv = reinterpret_cast<V*>(stage);
+    if (has) {
 #pragma unroll
-          for (int i = 0; i < D; ++i)
+      for (int g = 0; g < G; ++g) {
+        V v;
+        T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
-            for (int jj = 0; jj <= i; ++jj) A[i][jj] -= P[i][jj];
-        }
-        Chol<T, D> c;
-        bool f = false;
-        chol_lower<T, D>(A, c, f);
-        if (role == 0) {
-          if (f) {
-            fail = true;
-            report_fail(info, ((row0 + e + 1) << lvl_first) - 1);
-          }
-          T L[D][D];
-          chol_to_dense<T, D>(c, L);
-          store_block<T, D>(Dp + (lv.offD[j] + ge) * DD, L);
-          T Ol[D][D], G[D][D];
-          LT::load_blk(t.Oc, e - s + 1, Ol);
-          rsolve_lt_transposed<T, D>(c, Ol, G);
-          if (ge >= 1) store_block<T, D>(Gp + (lv.offG[j] + ge - 1) * DD, G);
-          syrk_lower<T, D>(W, G);
-        } else if (role == 1) {
-          if (has_o) {
-            T F[D][D];
-            LT::load_blk(t.Oc, e + 1, F);
-            rsolve_lt<T, D>(c, F);
-            store_block<T, D>(Fp + (lv.offF[j] + ge) * DD, F);
-            LT::load_blk(t.R, o, W);
-            if ((s > 1) && (o + h < K + 1 - kl)) {
-              T P[D][D];
-              LT::load_blk(t.R, o + h, P);
-#pragma unroll
-              for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int jj = 0; jj <= i; ++jj) W[i][jj] -= P[i][jj];
-            }
-            syrk_sub_lower<T, D>(W, F);
-            mirror_lower<T, D>(W);
-          }
-        } else if (has_o) {
-          T Ol[D][D], G[D][D], F[D][D];
-          LT::load_blk(t.Oc, e - s + 1, Ol);
-          rsolve_lt_transposed<T, D>(c, Ol, G);
-          LT::load_blk(t.Oc, e + 1, F);
-          const int i0 = (role == 2) ? 0 : DH, i1 = (role == 2) ? DH : D;
-#pragma unroll
-          for (int i = 0; i < D; ++i) {
-            if (i >= i0 && i < i1) {
-              fwd_subst<T, D>(c, F[i]);
-#pragma unroll
-              for (int jj = 0; jj < D; ++jj) {
-                T sacc = T(0);
-#pragma unroll
-                for (int m = 0; m < D; ++m) sacc = fmaT(-F[i][m], G[jj][m], sacc);
-                W[i][jj] = sacc;
-              }
-            }
-          }
-        }
+        for (int t = 0; t < VN; ++t) e[t] = A[(g * VN + t) / D][(g * VN + t) % D];
+        sv[k * G + (SWZ ? (g ^ (k & (G - 1))) : g)] = v;
       }
-      __syncthreads();
-      if (act) {
-        if (role == 0) {
-          LT::store_blk(t.R, e, W);
-        } else if (has_o) {
-          if (role == 1) LT::store_blk(t.R, o, W);
-          else if (role == 2) LT::template store_rows<0, DH>(t.Oc, e - s + 1, W);
-          else LT::template store_rows<DH, D>(t.Oc, e - s + 1, W);
-        }
-      }
-      __syncthreads();
     }
+    __builtin_amdgcn_wave_barrier();
+    V* dv = reinterpret_cast<V*>(dst);
+#pragma unroll 1
+    for (int v = first * G + lane; v < cnt * G; v += 64) {
+      const int kk = v / G, g = v % G;
+      dv[v] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    if (has) {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) stage[k * DD + a * D + b] = A[a][b];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int v = first * DD + lane; v < cnt * DD; v += 64) dst[v] = stage[v];
+    __builtin_amdgcn_wave_barrier();
   }
-  return levels;
 }
 
 // One pass of the factorisation.  FROM_RECORDS = false: rows are the caller's Rs / Os (level 0).
 // FROM_RECORDS = true: rows are the previous pass's records (RecordLayout without the vector
-// parts): R = Rs[w] + dRa[w+1], coupling to the previous row Cs[w].
+// parts): R = Rs[w] (+ dRa[w+1] for the last survivor of a tile, spt_in survivors per tile),
+// coupling to the previous row Cs[w].
+// The single tile of the last pass (rec_out == nullptr) runs lv.nlev <= DEC_MAXLEV levels until
+// nothing is left; otherwise lv.nlev <= 7 levels, then the surviving rows go to rec_out
+// (tile t, survivor m -> record t * (DEC_TS >> lv.nlev) + m; a tile's first record also carries DRA).
 template <typename T, int D, bool FROM_RECORDS>
 __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict__ Rin, const T* __restrict__ Oin,
-                                                             int64_t n, int64_t n_rec, DecompLevels lv,
+                                                             int64_t n, int64_t n_rec, int spt_in, DecompLevels lv,
                                                              int lvl_first,
                                                              T* __restrict__ Dp, T* __restrict__ Fp,
                                                              T* __restrict__ Gp, T* __restrict__ rec_out,
@@ -158,21 +136,11 @@ __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict
   constexpr int DD = D * D;
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  LdsTile<T, D> t;
-  t.R = reinterpret_cast<T*>(smem);
-  t.Oc = t.R + (size_t)DEC_TS * DD;
-  t.y = nullptr;
-  const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * DEC_TS;
-  const int n0 = (int)((n - row0) < DEC_TS ? (n - row0) : DEC_TS);
-  // A full tile running exactly LP levels ends with its last row still alive (odd at every one of
-  // those levels): that row is handed on as a record.  A ragged tile (only the last one can be)
-  // and the single tile of the top pass are reduced to nothing, by the reference's size rule.
-  const bool keep_last = (n0 == DEC_TS) && (lv.nlev == DEC_LP);
-  // rows of the tile -> LDS
-  if (tid < n0) {
-    const int64_t w = row0 + tid;
-    T R[D][D], C[D][D];
+  T* stage = reinterpret_cast<T*>(smem);          // 64 blocks: staging of the coalesced factor stores
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (n + DEC_TS - 1) / DEC_TS;
+
+  auto load_row = [&](int64_t w, T (&R)[D][D], T (&C)[D][D]) {     // row w of this pass and J[w, w-1]
     if constexpr (!FROM_RECORDS) {
       load_block<T, D>(Rin + w * DD, R);
       if (w >= 1) load_block<T, D>(Oin + (w - 1) * DD, C);
@@ -181,47 +149,169 @@ __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict
       const T* r = Rin + (size_t)w * RL::STRIDE;
       load_block<T, D>(r + RL::RS, R);
       load_block<T, D>(r + RL::CS, C);
-      // the update the next tile of the previous pass owes this row (every tile leaves a record,
-      // n_rec >= n of them: a ragged last tile has no row to hand on but still owes one)
-      if (w + 1 < n_rec) {
+      // only the last survivor of a tile of the previous pass is owed an update by the next
+      // tile, whose first record carries it (n_rec >= n: a tile without survivors still leaves one)
+      if (w + 1 < n_rec && (w + 1) % spt_in == 0) {
         T nR[D][D];
         load_block<T, D>(Rin + (size_t)(w + 1) * RL::STRIDE + RL::DRA, nR);
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+        for (int a = 0; a < D; ++a)
 #pragma unroll
-          for (int jj = 0; jj < D; ++jj) R[i][jj] += nR[i][jj];
+          for (int b = 0; b < D; ++b) R[a][b] += nR[a][b];
       }
     }
-    LdsTile<T, D>::store_blk(t.R, tid, R);
-    LdsTile<T, D>::store_blk(t.Oc, tid, C);        // Oc[i] = J[row i, row i-1]; Oc[0]: row left of the tile
-  }
-  __syncthreads();
-  bool fail = false;
-  const int levels = tile_cr_factor<T, D>(t, n0, keep_last, row0, lv, Dp, Fp, Gp, lvl_first, info, fail);
-  if (tid == 0 && rec_out != nullptr) {
-    // record: boundary row and its coupling to the previous tile's row (full tiles only), and what
-    // the previous tile's row is owed (every tile)
-    T Rs_[D][D], Cs_[D][D], dRa[D][D];
-    set_zero<T, D>(dRa);
-    for (int l = 0; l < levels; ++l) {
-      T P[D][D];
-      LdsTile<T, D>::load_blk(t.R, (1 << l) - 1, P);
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int jj = 0; jj <= i; ++jj) dRa[i][jj] -= P[i][jj];
+  };
+  // rows 2k (Re, its coupling Cl to row 2k-1) and 2k+1 (Ro, its coupling Cm to row 2k) of a tile
+  auto fetch = [&](int64_t tile, T (&Re)[D][D], T (&Cl)[D][D], T (&Ro)[D][D], T (&Cm)[D][D]) {
+    const int64_t row0 = tile * DEC_TS;
+    const int64_t w = row0 + 2 * lane;
+    if (w < n) load_row(w, Re, Cl);
+    if (w + 1 < n) load_row(w + 1, Ro, Cm);
+  };
+
+  auto process = [&](int64_t tile, T (&Re)[D][D], T (&Cl)[D][D], T (&Rr)[D][D], T (&Cm)[D][D]) {
+    const int64_t row0 = tile * DEC_TS;
+    const int n0 = (int)((n - row0) < DEC_TS ? (n - row0) : DEC_TS);
+    auto report = [&](int slot_row) { report_fail(info, ((row0 + slot_row + 1) << lvl_first) - 1); };
+    T Cc[D][D];                    // coupling of the row this lane carries (Rr) to the previous such row
+    T owed[D][D];                  // lane 0: minus what this tile owes the previous tile's last row
+    set_zero<T, D>(Cc);
+    set_zero<T, D>(owed);
+    int levels = 0;
+
+    // ---- level 0: lane k eliminates row 2k; row 2k+1 (if any) is the lane's level-1 row k -----
+    {
+      const bool act = 2 * lane < n0, has_o = 2 * lane + 1 < n0;
+      T UL[D][D], G[D][D];
+      set_zero<T, D>(UL);
+      set_zero<T, D>(G);
+      Chol<T, D> c;
+      const int64_t ge0 = row0 >> 1;
+      const int cntD = (n0 + 1) >> 1, cntF = n0 >> 1;
+      {
+        T L[D][D];
+        set_zero<T, D>(L);
+        if (act) {
+          bool f = false;
+          chol_lower<T, D>(Re, c, f);
+          if (f) report(2 * lane);
+          chol_to_dense<T, D>(c, L);
+        }
+        store_blocks_coalesced<T, D>(stage, Dp + (lv.offD[0] + ge0) * DD, L, act, lane, cntD, 0);
+      }
+      if (act) {
+        rsolve_lt_transposed<T, D>(c, Cl, G);                      // G = J[2k, 2k-1]^T D^-T
+        syrk_lower<T, D>(UL, G);                                   // owed to row 2k-1
+      }
+      store_blocks_coalesced<T, D>(stage, Gp + (lv.offG[0] + ge0 - 1) * DD, G, act, lane, cntD, ge0 == 0 ? 1 : 0);
+      {
+        T U[D][D];
+        shfl_lower<T, D>(U, UL, lane + 1);                         // what row 2k+2 owes row 2k+1
+        if (has_o && 2 * lane + 2 < n0) sub_lower<T, D>(Rr, U);
+      }
+      if (lane == 0) sub_lower<T, D>(owed, UL);
+      if (has_o) rsolve_lt<T, D>(c, Cm);                           // F = J[2k+1, 2k] D^-T
+      store_blocks_coalesced<T, D>(stage, Fp + (lv.offF[0] + ge0) * DD, Cm, has_o, lane, cntF, 0);
+      if (has_o) {
+        syrk_sub_lower<T, D>(Rr, Cm);
+        neg_abt<T, D>(Cc, Cm, G);                                  // J'[2k+1, 2k-1] = -F G^T
+      }
+      levels = 1;
     }
-    mirror_lower<T, D>(dRa);
-    set_zero<T, D>(Rs_);
-    set_zero<T, D>(Cs_);
-    if (keep_last) {
-      LdsTile<T, D>::load_blk(t.R, n0 - 1, Rs_);
-      LdsTile<T, D>::load_blk(t.Oc, 0, Cs_);
+
+    // ---- levels 1 .. nlev-1: row m of level j sits in lane (m+1) st - 1, st = 2^(j-1) ---------
+#pragma unroll 1
+    for (int j = 1; j < lv.nlev; ++j) {
+      const int M = n0 >> j;
+      if (M < 1) break;
+      const int st = 1 << (j - 1);
+      const bool on_grid = ((lane + 1) & (st - 1)) == 0;           // this lane holds a row of level j
+      const int m = ((lane + 1) >> (j - 1)) - 1;                   // its index
+      const bool exists = on_grid && m < M;
+      const bool even = exists && (m & 1) == 0, odd = exists && (m & 1) == 1;
+      const bool has_o = even && (m + 1 < M);
+      const int64_t ge0 = row0 >> (j + 1);                         // global index of the tile's first elimination
+      const int cntD = (M + 1) >> 1, cntF = M >> 1;
+      T G[D][D], F[D][D], U[D][D];
+      Chol<T, D> c;
+      set_zero<T, D>(G);
+      set_zero<T, D>(U);
+      shfl_block<T, D>(F, Cc, lane + st);                          // J[m+1, m] lives with row m+1
+      {
+        T L[D][D];
+        set_zero<T, D>(L);
+        if (even) {
+          bool f = false;
+          chol_lower<T, D>(Rr, c, f);
+          if (f) report(((lane + 1) << 1) - 1);
+          chol_to_dense<T, D>(c, L);
+        }
+        store_blocks_coalesced<T, D>(stage, Dp + (lv.offD[j] + ge0) * DD, L, even, m >> 1, cntD, 0);
+      }
+      if (even) {
+        rsolve_lt_transposed<T, D>(c, Cc, G);
+        syrk_lower<T, D>(U, G);                                    // owed to row m-1
+      }
+      store_blocks_coalesced<T, D>(stage, Gp + (lv.offG[j] + ge0 - 1) * DD, G, even, m >> 1, cntD, ge0 == 0 ? 1 : 0);
+      {
+        T V[D][D];
+        shfl_lower<T, D>(V, U, lane + st);
+        if (odd && m + 1 < M) sub_lower<T, D>(Rr, V);
+        shfl_lower<T, D>(V, U, st - 1);                            // the tile's first elimination: owed to the previous tile
+        if (lane == 0) sub_lower<T, D>(owed, V);
+      }
+      set_zero<T, D>(U);
+      if (has_o) rsolve_lt<T, D>(c, F);
+      store_blocks_coalesced<T, D>(stage, Fp + (lv.offF[j] + ge0) * DD, F, has_o, m >> 1, cntF, 0);
+      if (has_o) syrk_lower<T, D>(U, F);                           // owed to row m+1
+      {
+        T V[D][D];
+        shfl_lower<T, D>(V, U, lane - st);
+        if (odd) sub_lower<T, D>(Rr, V);
+      }
+      if (has_o) neg_abt<T, D>(U, F, G);                           // J'[m+1, m-1] = -F G^T
+      {
+        T V[D][D];
+        shfl_block<T, D>(V, U, lane - st);
+        if (odd) {
+#pragma unroll
+          for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) Cc[a][b] = V[a][b];
+        }
+      }
+      levels = j + 1;
     }
-    T* r = rec_out + (size_t)blockIdx.x * RL::STRIDE;
-    store_block<T, D>(r + RL::RS, Rs_);
-    store_block<T, D>(r + RL::CS, Cs_);
-    store_block<T, D>(r + RL::DRA, dRa);
+
+    if (rec_out == nullptr) return;
+    // ---- survivors -> records: after `levels` >= 1 levels the rows of level `levels` sit in
+    // lanes (m+1) 2^(levels-1) - 1
+    const int spt_out = DEC_TS >> lv.nlev;
+    const int nsurv = n0 >> levels;
+    const int st = 1 << (levels - 1);
+    const bool on_grid = ((lane + 1) & (st - 1)) == 0;
+    const int m = ((lane + 1) >> (levels - 1)) - 1;
+    if (on_grid && m < nsurv) {
+      mirror_lower<T, D>(Rr);
+      T* r = rec_out + ((size_t)tile * spt_out + m) * RL::STRIDE;
+      store_block<T, D>(r + RL::RS, Rr);
+      store_block<T, D>(r + RL::CS, Cc);
+    }
+    if (lane == 0) {
+      mirror_lower<T, D>(owed);
+      store_block<T, D>(rec_out + (size_t)tile * spt_out * RL::STRIDE + RL::DRA, owed);
+    }
+  };
+
+  // persistent wave: tiles blockIdx.x, + gridDim.x, ...  (a second register buffer that keeps the
+  // next tile's rows in flight was tried and is slower: the compiler's conservative vmcnt(0)
+  // waits around the stores drain the prefetch anyway, and it costs the registers)
+  T A0[D][D], A1[D][D], A2[D][D], A3[D][D];
+  set_zero<T, D>(A0); set_zero<T, D>(A1); set_zero<T, D>(A2); set_zero<T, D>(A3);   // lanes past the end of a
+#pragma unroll 1                                                                     // ragged tile fetch nothing
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    fetch(tile, A0, A1, A2, A3);
+    process(tile, A0, A1, A2, A3);
   }
 }
 
