@@ -724,7 +724,9 @@ template <typename T, int D> struct TileCfg {
   static constexpr int NT1 = 256;      // lanes (= threads) per workgroup in stage 1
   static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
   static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
-  static constexpr int RCMAX = 4;      // records a stage-3 lane eliminates sequentially before the LDS reduction
+  // records a stage-3 lane eliminates sequentially before the LDS reduction (8 x 8 blocks: that
+  // one-lane code spills, more workgroups with one record per lane are faster)
+  static constexpr int RCMAX = (D == 8) ? 1 : 4;
   // lanes sharing one block row in stage 1 (cgps_tile_ml.h): 8 x 8 blocks do not fit one lane's registers
   static constexpr int LPR = (D == 8) ? 4 : 1;
   static constexpr int NG1 = NT1 / LPR;                 // kept rows (= LDS tile slots) per stage-1 workgroup

@@ -127,7 +127,7 @@ int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t 
  * distances between consecutive shards' records / partials, so both can be read in place from
  * the receive buffer of an all-gather of [record | partial] messages (record_out and
  * partial_out of cgps_shard_reduce may point straight into the send buffer; partial_out must
- * be 8-byte aligned).  P <= 1024.  Built for every block size whose 256-row tile fits the LDS:
+ * be 8-byte aligned).  P <= 1024 (256 for d = 8).  Built for every block size whose 256-row tile fits the LDS:
  * fp64 d <= 5 and fp32 d <= 8 (CGPS_ERR_UNSUPPORTED otherwise). */
 int cgps_record_elems(int d, int dtype, int64_t* elems);
 int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void* O_left, int64_t n_loc, int d,
