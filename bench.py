@@ -116,7 +116,43 @@ def extra_measurements(dev):
             torch.cuda.empty_cache()
         except Exception as e:  # keep the headline line alive whatever happens here
             out[name] = {"error": repr(e)[:200]}
+    # BASELINE config 1 (N=1024, d=2, fp64): the launch-latency end of the path
+    try:
+        Rs, Os, b, x_true, logdet_true = make_system(1024, 2, torch.float64, dev)
+        holder = {}
+
+        def dec1():
+            holder["dec"] = cr.decompose(Rs, Os)
+        out["c1_N1024_d2_f64"] = {
+            "mahal_and_det_us": _time_cuda(lambda: cr.mahal_and_det(Rs, Os, b), 50) * 1e6,
+            "decompose_us": _time_cuda(dec1, 50) * 1e6,
+            "solve_us": _time_cuda(lambda: cr.solve(holder["dec"], b), 50) * 1e6,
+            "logdet_rel_err": abs(float(cr.mahal_and_det(Rs, Os, b)[1]) - logdet_true) / abs(logdet_true),
+        }
+    except Exception as e:
+        out["c1_N1024_d2_f64"] = {"error": repr(e)[:200]}
     cr.CHECK_POSITIVE_DEFINITE = True
+    # BASELINE config 5: LEG log-likelihood + posterior mean on the CO2-shaped series (N=502, rank 5),
+    # parameters and expected values from the fixture recorded from the reference
+    try:
+        import numpy as np
+        from cyclic_gps import leg
+        g = np.load(os.path.join(ROOT, "tests", "golden", "leg_co2like.npz"))
+        t = lambda k: torch.from_numpy(g[k]).to(torch.float64).to(dev)   # noqa: E731
+        m = leg.LEGMatrices(t("N"), t("R"), t("B"), t("Lambda"))
+        ts, xs = t("ts"), t("xs")
+        ll = leg.log_likelihood(m, ts, xs)
+        mean = leg.insample_posterior(m, ts, xs)[0]
+        res = {"rows": int(ts.shape[0]), "rank": int(m.G.shape[0]),
+               "log_likelihood_us": _time_cuda(lambda: leg.log_likelihood(m, ts, xs), 10) * 1e6,
+               "insample_posterior_us": _time_cuda(lambda: leg.insample_posterior(m, ts, xs), 10) * 1e6,
+               "ll_rel_err_vs_reference": abs(float(ll) - float(g["ll"])) / abs(float(g["ll"]))}
+        if "post_mean" in g.files:
+            res["posterior_mean_max_abs_err_vs_reference"] = float(
+                (mean.cpu() - torch.from_numpy(g["post_mean"])).abs().max())
+        out["c5_leg_co2like"] = res
+    except Exception as e:
+        out["c5_leg_co2like"] = {"error": repr(e)[:200]}
     return out
 
 

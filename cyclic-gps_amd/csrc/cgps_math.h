@@ -37,6 +37,20 @@ __device__ __forceinline__ float rsqrt_fast(float s) {
   return r;
 }
 
+// ---- reciprocal -----------------------------------------------------------------
+// hardware estimate + Newton steps (a full IEEE division is ~20 instructions in fp64)
+__device__ __forceinline__ double rcp_fast(double s) {
+  double r = __builtin_amdgcn_rcp(s);
+  r = __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float rcp_fast(float s) {
+  float r = __builtin_amdgcn_rcpf(s);
+  r = __builtin_fmaf(__builtin_fmaf(-s, r, 1.0f), r, r);
+  return r;
+}
+
 // A lower-triangular Cholesky factor kept as its strict lower part, its
 // diagonal and the reciprocal diagonal (so substitutions multiply, never divide).
 template <typename T, int D>
@@ -191,7 +205,7 @@ __device__ __forceinline__ void chol_from_dense(const T (&L)[D][D], Chol<T, D>& 
   for (int i = 0; i < D; ++i) {
 #pragma unroll
     for (int j = 0; j <= i; ++j) c.l[i][j] = L[i][j];
-    c.inv[i] = T(1) / L[i][i];
+    c.inv[i] = rcp_fast(L[i][i]);
   }
 }
 
