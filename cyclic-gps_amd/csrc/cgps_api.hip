@@ -12,6 +12,7 @@
 #include "cgps_tile.h"
 #include "cgps_solve_tile.h"
 #include "cgps_decomp_tile.h"
+#include "cgps_decomp_lds.h"
 #include <cstdlib>
 
 namespace {
@@ -362,7 +363,8 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   return check_launch("inverse_blocks");
 }
 
-// ---- fused (tiled) factorisation: cgps_decomp_tile.h ------------------------------------------
+// ---- fused (tiled) factorisation: cgps_decomp_tile.h (bulk passes) + cgps_decomp_lds.h (tail) ----
+constexpr int64_t DEC_SMALL_ROWS = 32768;   // at or below this many rows a pass is latency-bound
 template <typename T, int D>
 int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
                        hipStream_t st) {
@@ -388,9 +390,43 @@ int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp,
   const T* rin = nullptr;
   int64_t n_rec = 0;
   int lvl = 0, p = 0, spt_in = 1;
+  const size_t lds_small = cgps::decomp_lds_tile_bytes<T, D>();
+  static bool small_attr_done = false;
+  if (!small_attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    small_attr_done = true;
+  }
   while (lvl < L.nlevels) {
     const int64_t rows = L.ms[lvl];
     const int remaining = L.nlevels - lvl;
+    if (rows <= DEC_SMALL_ROWS) {
+      // latency-bound tail (or a small system): 256-row tiles in LDS, 8 levels per launch, four
+      // waves per elimination (cgps_decomp_lds.h); one record per tile
+      const int64_t g = (rows + cgps::DECL_TS - 1) / cgps::DECL_TS;
+      const int nl = (g == 1) ? remaining : cgps::DECL_LP;                 // <= DECL_LP + 1
+      cgps::DecompLevelsL dl;
+      dl.nlev = nl;
+      for (int j = 0; j < cgps::DECL_MAXLEV; ++j) {
+        const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+        dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+      }
+      T* rout = recs[p & 1];
+      if (p == 0)
+        hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, false>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds_small, st,
+                           Rs, Os, rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
+      else
+        hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, true>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds_small, st,
+                           rin, (const T*)nullptr, rows, n_rec, spt_in, dl, lvl, Dp, Fp, Gp, rout, info);
+      rin = rout;
+      n_rec = g;
+      spt_in = 1;
+      lvl += nl;
+      ++p;
+      continue;
+    }
     const int64_t g = (rows + cgps::DEC_TS - 1) / cgps::DEC_TS;
     const bool top = g == 1;                                               // one tile takes it to the end
     // many tiles: a few levels per pass keep the lanes busy; few tiles: all levels of a tile
