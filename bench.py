@@ -104,8 +104,10 @@ def extra_measurements(dev):
                 t_dec = _time_cuda(dec, reps)
                 t_sol = _time_cuda(lambda: cr.solve(holder["dec"], b), reps)
                 t_det = _time_cuda(lambda: cr.det(holder["dec"]), reps)
+                t_inv = _time_cuda(lambda: cr.inverse_blocks(holder["dec"]), max(2, reps // 3))
                 xs = cr.solve(holder["dec"], b)
                 res.update(decompose_us=t_dec * 1e6, solve_us=t_sol * 1e6, det_us=t_det * 1e6,
+                           inverse_blocks_us=t_inv * 1e6,
                            decompose_GBps=5.0 * n * d * d * s / t_dec / 1e9,
                            solve_GBps=(3.0 * n * d * d + 2.0 * n * d) * s / t_sol / 1e9,
                            factor_solves_per_s=1.0 / (t_dec + t_sol),

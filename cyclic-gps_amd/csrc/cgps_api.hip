@@ -165,13 +165,16 @@ struct SolvePasses {
   int64_t rows[8];
 };
 
-void make_passes(const Layout& L, SolvePasses& P) {
+void make_passes(const Layout& L, SolvePasses& P, int wide_lp) {
   P.np = 0;
   int lvl = 0;
   while (lvl < L.nlevels) {
     const int64_t rows = L.ms[lvl];
     const int remaining = L.nlevels - lvl;
-    const int nl = (rows <= cgps::SOLVE_TS) ? remaining : cgps::SOLVE_LP;   // <= SOLVE_LP + 1
+    // many tiles: a few levels per pass (every lane busy, few barrier-separated latency
+    // exposures, the factor still read once); few tiles: all ten levels of a tile
+    const int nl = (rows <= cgps::SOLVE_TS) ? remaining
+                   : (rows >= cgps::SOLVE_WIDE_ROWS ? wide_lp : cgps::SOLVE_LP);   // <= SOLVE_LP + 1
     cgps::PassLevels& pl = P.lv[P.np];
     pl.nlev = nl;
     pl.endD = L.offD[lvl + nl];
@@ -218,7 +221,7 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P);
+  make_passes(L, P, cgps::SOLVE_LP_WIDE);
   solve_tile_attributes<T, D>();
   double* partial = reinterpret_cast<double*>(ws + w.partial_off);
   T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
@@ -226,17 +229,21 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   const T* y = y0;
   const T* owed_in = nullptr;
   int64_t n_owed = 0, pb = 0;
+  int spt_in = 1;
   for (int p = 0; p < P.np; ++p) {
     const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
     const bool more = (p + 1 < P.np);
-    T* yout = more ? bufs[p & 1] : nullptr;            // [g][D] surviving rows, then [g][D] owed vectors
-    T* owed_out = more ? bufs[p & 1] + g * D : nullptr;
+    const int64_t nsurv = n >> P.lv[p].nlev;           // rows of the next pass
+    T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D] surviving rows, then [g][D] owed vectors
+    T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * D : nullptr;
     hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
-                       P.lv[p], owed_in, n_owed, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+                       P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
     pb += g;
     y = yout;
     owed_in = owed_out;
     n_owed = g;
+    spt_in = cgps::SOLVE_TS >> P.lv[p].nlev;
+    if (spt_in < 1) spt_in = 1;
   }
   if (mahal_out) {
     double* tmp = partial + 2 * pb;  // one spare slot was reserved
@@ -255,7 +262,7 @@ int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P);
+  make_passes(L, P, cgps::SOLVE_LP_WIDE);      // (the two sweeps need not use the same passes; 3 / 3 measured best)
   solve_tile_attributes<T, D>();
   T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
                 reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};

@@ -24,8 +24,9 @@
 //     parities agree at every level of a pass;
 //   * what a tile's first eliminations owe the previous tile's last row travels as the DRA part
 //     of the tile's first record and is added when the next pass loads that row.
-// N = 2^20: five launches (2^20 -> 2^17 -> 2^14 -> 2^7 -> done), every input block read once,
-// survivors written and re-read once per pass.
+// The host runs these passes while more than 2^15 rows are left and hands the latency-bound tail
+// to cgps_decomp_lds.h.  N = 2^20: 2^20 -> 2^17 -> 2^14 here, then 2^14 -> 64 -> done there; every
+// input block is read once, survivors are written and re-read once per pass.
 #pragma once
 #include "cgps_tile.h"
 

@@ -6,8 +6,11 @@
 // only state that must be shared between rows is the right-hand side: 8 d bytes per row.  So a
 // workgroup keeps the vectors of a TS = 1024-row tile in LDS and walks LP = 10 reduction levels
 // over them, while the D / F / G blocks of each level stream from HBM exactly once (consecutive
-// lanes read consecutive blocks of the level's packed array).  N = 2^20 needs two launches per
-// sweep instead of 21.
+// lanes read consecutive blocks of the level's packed array).  While the system is large
+// (>= 2^20 rows) a pass runs only SOLVE_LP_WIDE = 3 levels -- 512 + 256 + 128 eliminations on
+// 512 lanes, 6 barrier-separated phases instead of 20 -- and hands the 128 surviving rows of
+// every tile to the next pass; smaller systems are latency-bound and run all ten levels.
+// N = 2^20 needs three launches per sweep instead of 21.
 //
 // In-place indexing: row r of local level j lives in slot (r + 1) 2^j - 1 of the tile, i.e. every
 // row stays where it was at local level 0; eliminated rows' slots are reused for x.
@@ -24,6 +27,8 @@ constexpr int SOLVE_LP = 10;            // levels per pass
 constexpr int SOLVE_TS = 1 << SOLVE_LP; // rows per tile
 constexpr int SOLVE_NT = 512;           // threads per workgroup (= eliminations of a tile's level 0)
 constexpr int SOLVE_MAXLEV = SOLVE_LP + 1;
+constexpr int SOLVE_LP_WIDE = 3;                  // levels per pass while the system is large ...
+constexpr int64_t SOLVE_WIDE_ROWS = 1 << 20;      // ... i.e. has at least this many rows (2^18 .. 2^20 measured alike)
 template <typename T, int D> constexpr size_t solve_lds_bytes() {
   return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double);
 }
@@ -63,13 +68,15 @@ __device__ __forceinline__ void lds_store_vec(T* p, const T (&v)[D]) {
 //         surviving rows, each still missing what the NEXT tile's first rows owe it: owed_in[t] =
 //         sum over that pass's levels j of G_j x_j for tile t's first row (n_owed entries);
 //         row i takes owed_in[i + 1].
-// xcrr  : output, CRR layout (Dp offsets).   y_out : this pass's surviving rows (one per full tile).
-// owed_out[tile] : what this tile's first rows owe the previous tile's surviving row.
+// xcrr  : output, CRR layout (Dp offsets).   y_out : this pass's surviving rows (SOLVE_TS >> nlev per
+//         full tile; tile t, survivor r -> y_out[t * (SOLVE_TS >> nlev) + r]).
+// owed_out[tile] : what this tile's first rows owe the previous tile's LAST surviving row
+//         (spt_in = survivors per tile of the pass that wrote owed_in).
 template <typename T, int D>
 __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
-    const T* __restrict__ owed_in, int64_t n_owed, const T* __restrict__ y_in, int64_t n, T* __restrict__ xcrr,
-    T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
+    const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int64_t n,
+    T* __restrict__ xcrr, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
   constexpr int DD = D * D;
   extern __shared__ __attribute__((aligned(16))) char solve_smem[];
   T* ys = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
@@ -86,9 +93,11 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
   for (int r = tid; r < n0; r += SOLVE_NT) {
     T v[D];
     load_vec<T, D>(y_in + (row0 + r) * D, v);
-    if (owed_in != nullptr && row0 + r + 1 < n_owed) {
+    // only the last survivor of a tile of the previous pass (spt_in survivors per tile) is owed
+    const int64_t wn = row0 + r + 1;
+    if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {
       T w[D];
-      load_vec<T, D>(owed_in + (row0 + r + 1) * D, w);
+      load_vec<T, D>(owed_in + (wn / spt_in) * D, w);
 #pragma unroll
       for (int i = 0; i < D; ++i) v[i] -= w[i];
     }
@@ -142,10 +151,13 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
     __syncthreads();
     nj = no;
   }
-  if (nj == 1 && y_out != nullptr && tid == 0) {         // the tile's surviving row (full tiles only)
-    T v[D];
-    lds_load_vec<T, D>(ys + (size_t)(SOLVE_TS - 1) * D, v);
-    store_vec<T, D>(y_out + (size_t)blockIdx.x * D, v);
+  if (y_out != nullptr) {                                // the tile's surviving rows: nj = n0 >> nlev of them
+    const int spt_out = SOLVE_TS >> lv.nlev;
+    for (int r = tid; r < nj; r += SOLVE_NT) {
+      T v[D];
+      lds_load_vec<T, D>(ys + (size_t)(((r + 1) << lv.nlev) - 1) * D, v);
+      store_vec<T, D>(y_out + ((size_t)blockIdx.x * spt_out + r) * D, v);
+    }
   }
   if (owed_out != nullptr && tid == 0) store_vec<T, D>(owed_out + (size_t)blockIdx.x * D, owed);
   block_sum2<SOLVE_NT>(mah, zero, red);
@@ -178,12 +190,13 @@ __global__ __launch_bounds__(SOLVE_NT) void backsolve_tile_kernel(
   T xleft[D];                                            // x of the previous tile's last row
 #pragma unroll
   for (int i = 0; i < D; ++i) xleft[i] = T(0);
-  if (x_coarse != nullptr) {
-    if (blockIdx.x > 0) load_vec<T, D>(x_coarse + ((size_t)blockIdx.x - 1) * D, xleft);
-    if (tid == 0 && n0 == SOLVE_TS) {                    // own surviving row
+  if (x_coarse != nullptr) {                             // solution of the rows that survived this pass's levels
+    const int spt = SOLVE_TS >> lv.nlev;                 // per full tile, natural order
+    if (blockIdx.x > 0) load_vec<T, D>(x_coarse + ((size_t)blockIdx.x * spt - 1) * D, xleft);
+    for (int r = tid; r < (n0 >> lv.nlev); r += SOLVE_NT) {
       T v[D];
-      load_vec<T, D>(x_coarse + (size_t)blockIdx.x * D, v);
-      lds_store_vec<T, D>(xs + (size_t)(SOLVE_TS - 1) * D, v);
+      load_vec<T, D>(x_coarse + ((size_t)blockIdx.x * spt + r) * D, v);
+      lds_store_vec<T, D>(xs + (size_t)(((r + 1) << lv.nlev) - 1) * D, v);
     }
   }
   __syncthreads();
