@@ -149,6 +149,9 @@ def extra_measurements(dev):
                "log_likelihood_us": _time_cuda(lambda: leg.log_likelihood(m, ts, xs), 10) * 1e6,
                "insample_posterior_us": _time_cuda(lambda: leg.insample_posterior(m, ts, xs), 10) * 1e6,
                "ll_rel_err_vs_reference": abs(float(ll) - float(g["ll"])) / abs(float(g["ll"]))}
+        # the same evaluation with a gradient wanted: operand assembly by batched torch ops (autograd)
+        mg = leg.LEGMatrices(t("N").requires_grad_(True), t("R"), t("B"), t("Lambda"))
+        res["log_likelihood_with_grad_graph_us"] = _time_cuda(lambda: leg.log_likelihood(mg, ts, xs), 5) * 1e6
         if "post_mean" in g.files:
             res["posterior_mean_max_abs_err_vs_reference"] = float(
                 (mean.cpu() - torch.from_numpy(g["post_mean"])).abs().max())

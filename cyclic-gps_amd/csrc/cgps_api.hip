@@ -13,6 +13,7 @@
 #include "cgps_solve_tile.h"
 #include "cgps_decomp_tile.h"
 #include "cgps_decomp_lds.h"
+#include "cgps_leg.h"
 #include <cstdlib>
 
 namespace {
@@ -728,6 +729,22 @@ int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t 
     constexpr int D = decltype(dc)::value;
     return run_inverse<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (T*)Sd, (T*)So, (char*)ws, ws_bytes,
                              (hipStream_t)stream);
+  });
+}
+
+int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtype, void* Rs, void* Os, int* info,
+                       void* stream) {
+  if (bad_common(N, d) || !ts || !G || !Rs || (N > 1 && !Os) || !info)
+    return fail(CGPS_ERR_ARG, "cgps_peg_precision: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(info, 0, sizeof(int), st);
+    const int64_t nb = (N + cgps::LEG_THREADS - 1) / cgps::LEG_THREADS;
+    hipLaunchKernelGGL((cgps::peg_precision_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEG_THREADS), 0, st,
+                       (const T*)ts, (const T*)G, N, (T*)Rs, (T*)Os, info);
+    return check_launch("peg_precision");
   });
 }
 

@@ -52,9 +52,32 @@ class LEGMatrices:
         return self.Lambda @ self.Lambda.T + 1e-9 * torch.eye(o, dtype=self.Lambda.dtype, device=self.Lambda.device)
 
 
+def _peg_precision_hip(ts, G):
+    """The same blocks from one HIP kernel (cgps_peg_precision, csrc/cgps_leg.h): one lane per block
+    row, matrix exponential and the two small solves in registers.  No autograd graph."""
+    from . import _hip
+    n, d = ts.shape[0], G.shape[0]
+    ts = ts.to(G.dtype).contiguous()
+    G = G.contiguous()
+    Rs = torch.empty(n, d, d, dtype=G.dtype, device=G.device)
+    Os = torch.empty(max(n - 1, 0), d, d, dtype=G.dtype, device=G.device)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    _hip.check(_hip.lib().cgps_peg_precision(_hip.ptr(ts), _hip.ptr(G), n, d, _hip.dtype_code(G.dtype), _hip.ptr(Rs),
+                                             _hip.ptr(Os), _hip.ptr(info), _hip.stream_ptr()))
+    if cr.CHECK_POSITIVE_DEFINITE:
+        bad = int(info.item())
+        if bad:
+            raise cr.NotPSDError("time gap next to row %d gives a singular PEG block (zero-length gap?)" % (bad - 1))
+    return Rs, Os
+
+
 def peg_precision(ts, G):
-    """Diagonal and lower off-diagonal blocks of the PEG prior precision (models.py:181-239)."""
+    """Diagonal and lower off-diagonal blocks of the PEG prior precision (models.py:181-239).
+    On the GPU, when no gradient is wanted, one HIP kernel; otherwise batched torch ops (autograd)."""
     d = G.shape[0]
+    wants_grad = torch.is_grad_enabled() and (G.requires_grad or ts.requires_grad)
+    if G.is_cuda and ts.is_cuda and not wants_grad and 1 <= d <= 8 and G.dtype in (torch.float32, torch.float64):
+        return _peg_precision_hip(ts, G)
     eye = torch.eye(d, dtype=G.dtype, device=G.device)
     dt = ts[1:] - ts[:-1]
     E = torch.matrix_exp(-0.5 * G.unsqueeze(0) * dt.reshape(-1, 1, 1))

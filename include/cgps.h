@@ -112,6 +112,15 @@ int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype,
 int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
                         void* Sd, void* So, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- operand assembly for LEG models (the caller's step right before the path) ---------------
+ * Blocks of the PEG prior precision from the time stamps and the generator G
+ * (models.py:181-239: E_i = exp(-1/2 (t_{i+1}-t_i) G), two d x d solves per gap):
+ * ts[N] (same dtype as the blocks), G[d][d]  ->  Rs[N][d][d], Os[N-1][d][d].
+ * info: 0, or 1 + the index of a row next to a gap whose systems are not positive definite
+ * (zero-length gap, NaN).  No workspace. */
+int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtype,
+                       void* Rs, void* Os, int* info, void* stream);
+
 /* ---- time-axis sharding (one shard per GPU / rank) -----------------------------------------
  * The reference has no distributed code; this is the multi-GPU form BASELINE.json asks for.
  * A shard is n_loc consecutive block rows: Rs[n_loc], Os[n_loc-1] (couplings INSIDE the shard),

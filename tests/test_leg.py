@@ -73,3 +73,56 @@ def test_posterior_mean_fp32_within_1e4():
     mean, _ = leg.insample_posterior(m, ts, xs)
     err = np.abs(mean.cpu().double().numpy() - g["post_mean"]).max()
     assert err <= 1e-4 * max(1.0, np.abs(g["post_mean"]).max()), err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_hip_operand_assembly_matches_reference(name):
+    """cgps_peg_precision (one HIP kernel) against the blocks recorded from the reference."""
+    g, m, ts, xs = _load(name, device="cuda")
+    Rs, Os = leg._peg_precision_hip(ts, m.G)
+    np.testing.assert_allclose(Rs.cpu().numpy(), g["Sig_Rs"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Os.cpu().numpy(), g["Sig_Os"], rtol=1e-9, atol=1e-11)
+    # the dispatcher takes the kernel when no gradient is wanted and torch ops when one is
+    Rs2, _ = leg.peg_precision(ts, m.G)
+    assert Rs2.grad_fn is None and torch.equal(Rs2, Rs)
+    Gg = m.G.clone().requires_grad_(True)
+    Rs3, _ = leg.peg_precision(ts, Gg)
+    assert Rs3.grad_fn is not None
+    np.testing.assert_allclose(Rs3.detach().cpu().numpy(), Rs.cpu().numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_hip_operand_assembly_against_torch_ops(d, dtype):
+    """Every block size, irregular gaps over three orders of magnitude (scaling and squaring of
+    the exponential exercised from s = 0 to s ~ 10), against the batched torch restatement.
+    Small gaps make I - E^T E nearly singular (blocks ~ 1/gap), so the two ways of solving it
+    (Cholesky here, LU in torch) agree to cond * eps, not to eps: hence the tolerances."""
+    gen = torch.Generator().manual_seed(40 + d)
+    Nm = 0.6 * torch.randn(d, d, generator=gen, dtype=torch.float64).tril()
+    Rm = 0.4 * torch.randn(d, d, generator=gen, dtype=torch.float64).tril(-1)
+    G = (Nm @ Nm.T + Rm - Rm.T + 1e-5 * torch.eye(d, dtype=torch.float64)).to(dtype)
+    lo = -1.0 if dtype == torch.float64 else 0.0     # fp32: I - E^T E cancels for gaps << 1, in any implementation
+    gaps = 10.0 ** (torch.rand(700, generator=gen, dtype=torch.float64) * (2 - lo) + lo)   # 0.1 (1) .. 100
+    ts = torch.cat([torch.zeros(1, dtype=torch.float64), gaps.cumsum(0)]).to(dtype)
+    Gd = G.double().cuda().requires_grad_(True)                                         # forces the torch-op path
+    rRs, rOs = leg.peg_precision(ts.double().cuda(), Gd)
+    Rs, Os = leg.peg_precision(ts.cuda(), G.cuda())
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == torch.float64 else dict(rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(Rs.double().cpu().numpy(), rRs.detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(Os.double().cpu().numpy(), rOs.detach().cpu().numpy(), **tol)
+    if d == 3 and dtype == torch.float64:                                               # one system of one row
+        R1, O1 = leg.peg_precision(ts[:1].cuda(), G.cuda())
+        assert R1.shape == (1, d, d) and O1.shape == (0, d, d)
+        assert torch.equal(R1[0].cpu(), torch.eye(d, dtype=dtype))
+
+
+@pytest.mark.gpu
+def test_hip_operand_assembly_reports_a_zero_gap():
+    g, m, ts, xs = _load("leg_small_regular", device="cuda")
+    ts = ts.clone()
+    ts[5] = ts[4]
+    with pytest.raises(leg.cr.NotPSDError):
+        leg.peg_precision(ts, m.G)
