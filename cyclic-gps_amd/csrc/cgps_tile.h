@@ -734,9 +734,21 @@ template <typename T, int D> struct TileCfg {
 };
 // TileCfg<T, d>::ROWS1 for a run-time d (workspace sizing)
 inline int64_t tile_rows1(int d) { return d == 8 ? 64 * 256 / 4 : 16 * 256; }
+// Below ~2^19 rows the op is pure latency and stage 1's sequential chain of C - 1 eliminations
+// per lane is most of it.  Small systems therefore take fewer rows per lane: the smallest C of
+// {1, 4, 8, C_full} that keeps the grid within one workgroup per CU (more lanes, shorter chains,
+// the same number of records for the final stage or fewer).
+constexpr int64_t STAGE1_SMALL_TILES = 256;
+inline int stage1_rows_per_lane(int64_t N, int c_full, int lanes) {
+  if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 1) return 1;
+  if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 4) return 4;
+  if (c_full > 8 && N <= STAGE1_SMALL_TILES * lanes * 8) return 8;
+  return c_full;
+}
+inline int64_t tile_cap(int64_t N, int d) { return N / tile_rows1(d) + 2 + STAGE1_SMALL_TILES; }
 
 inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
-  const int64_t tiles = N / tile_rows1(d) + 2;
+  const int64_t tiles = tile_cap(N, d);
   const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
   const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
@@ -751,9 +763,16 @@ void tile_set_attributes() {
   if constexpr (Cfg::LPR > 1)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-  else
+  else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 8, Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 4, Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 1, Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
@@ -773,10 +792,11 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   using Cfg = TileCfg<T, D>;
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
-  const int64_t rows_per_tile = Cfg::ROWS1;
-  if (rows_per_tile != tile_rows1(D)) return -1;        // the two definitions of ROWS1 must agree
+  if (Cfg::ROWS1 != tile_rows1(D)) return -1;           // the two definitions of ROWS1 must agree
+  const int csel = (Cfg::LPR > 1) ? Cfg::C : stage1_rows_per_lane(N, Cfg::C, Cfg::NT1);
+  const int64_t rows_per_tile = (int64_t)csel * Cfg::NG1;
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
-  const int64_t tiles_cap = N / tile_rows1(D) + 2;
+  const int64_t tiles_cap = tile_cap(N, D);
   double* partial = reinterpret_cast<double*>(ws);
   const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   T* recA = reinterpret_cast<T*>(ws + pbytes);
@@ -787,6 +807,15 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   if constexpr (Cfg::LPR > 1)
     hipLaunchKernelGGL((chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>), dim3((unsigned)tiles), dim3(Cfg::NT1),
                        lds1, st, Rs, Os, x, N, Oleft, recA, partial);
+  else if (csel == 1)
+    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 1, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                       Rs, Os, x, N, Oleft, recA, partial);
+  else if (csel == 4)
+    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 4, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                       Rs, Os, x, N, Oleft, recA, partial);
+  else if (csel == 8)
+    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 8, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                       Rs, Os, x, N, Oleft, recA, partial);
   else
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                        Rs, Os, x, N, Oleft, recA, partial);

@@ -85,6 +85,8 @@ def test_ragged_sizes_against_oracle(d, dtype):
         sizes += [65537, 66049, 131073]   # (d = 8: the four-lanes-per-row streaming kernel, 4096-row tiles)
     if d == 8:
         sizes += [4095, 4096, 8191, 8193, 12289]
+    if d == 4:              # every rows-per-lane regime of the fused solve + log-det (1, 4, 8 rows per lane; 16: full-size tests)
+        sizes += [65536, 262143, 262145, 300001, 524287]
     for n in sizes:
         Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, seed=100 + n)
         ref_m, ref_ld = O.mahal_and_det(Rs, Os, b)
