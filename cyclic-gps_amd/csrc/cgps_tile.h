@@ -30,6 +30,8 @@
 // last REAL row, which is what lets a shard of a larger system (one per GPU) be
 // reduced by the same code to a single record the next shard couples to.
 #pragma once
+#include <type_traits>
+
 #include "cgps_level.h"
 
 namespace cgps {
@@ -229,6 +231,12 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 #define CGPS_STAMP(slot) do { } while (0)
 #endif
 
+#include "cgps_tile_mfma.h"
+// a level goes to the 16-lanes-per-elimination form when it has at most this many eliminations
+// (one pass of four waves; measured: 1.2 us against 2.2-2.6 us for a role-split pass, while two
+// such passes, or one with eight waves, are no faster than the role-split form)
+constexpr int MFMA_LEVEL_MAX_ELIMS = 16;
+
 template <typename T, int D, int NTHR>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
                                        long long* stamps = nullptr) {
@@ -246,6 +254,13 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
   for (int s = 1; (s - 1) < K; s <<= 1, ++levels) {
     const int M = (K + 1) / s, h = s >> 1;
     const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
+    if constexpr (std::is_same<T, double>::value && D == 4) {
+      // narrow level: sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h)
+      if (n_elim <= MFMA_LEVEL_MAX_ELIMS) {
+        tile_cr_level_mfma<NTHR>(t, K, M, s, pl, mah, fail);
+        continue;
+      }
+    }
 #pragma unroll 1
     for (int k0 = 0; k0 < n_elim; k0 += 64 * NGRP) {
       const int k = k0 + 64 * grp + lane;
@@ -290,6 +305,7 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
           LT::load_blk(t.Oc, e - s + 1, Ol);
           rsolve_lt_transposed<T, D>(c, Ol, G);
           syrk_lower<T, D>(W, G);
+          mirror_lower<T, D>(W);                   // parked blocks are stored symmetric (cgps_tile_mfma.h reads all of it)
           set_zero<T, D>(wv);
 #pragma unroll
           for (int i = 0; i < D; ++i)
