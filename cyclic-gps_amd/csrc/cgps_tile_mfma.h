@@ -21,10 +21,12 @@
 // matrix kept in the "standard" layout (element [r][c] in lane 16r+4b+c) that reads
 //     mfma(X, Y, C) = X^T Y + C.
 
-// element [r][c] of the block in `slot` (the granule swizzle of LdsTile<double, 4>)
-__device__ __forceinline__ int mfma_elem_offset(int slot, int r, int c) {
-  const int idx = r * 4 + c;
-  return slot * 16 + ((((idx >> 1) ^ LdsTile<double, 4>::key(slot)) << 1) | (idx & 1));
+// double-offset of granule-element (g, tb) -- g = (4 r + c) / 2, tb = (4 r + c) % 2 -- of the block
+// in `slot`: the granule swizzle of LdsTile<double, 4> (its key() without the >> 9 fold: the
+// tile of this path has at most 257 slots)
+__device__ __forceinline__ int mfma_elem_offset(int slot, int g, int tb) {
+  const int key = (slot ^ (slot >> 3) ^ (slot >> 6)) & 7;
+  return slot * 16 + (((g ^ key) << 1) | tb);
 }
 
 template <int Q>
@@ -48,6 +50,9 @@ __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K,
   const int h = s >> 1;
   const int n_elim = (M + 1) / 2;
   const double ident = (r == c) ? 1.0 : 0.0;
+  const int g = (4 * r + c) >> 1, tb = c & 1;                   // this lane's element, straight and
+  const int gT = (4 * c + r) >> 1, tT = r & 1;                  // transposed
+  const bool c0 = (c == 0);
 #pragma unroll 1
   for (int k0 = 0; k0 < n_elim; k0 += NTHR / 16) {
     if (k0 + 4 * wave >= n_elim) continue;                       // (wave-uniform) nothing for this wave
@@ -57,23 +62,27 @@ __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K,
     const int o = (2 * k + 1 < M) ? e + s : K;
     const bool pend_e = act && (s > 1) && (e + h < K);
     const bool pend_o = act && (s > 1) && (o + h < K);
-    // ---- operands: one element per lane --------------------------------------------------
+    // ---- operands: one element per lane (y: every lane reads its row's entry, column 0 keeps it) --
+    const int oRe = mfma_elem_offset(e, g, tb), oRo = mfma_elem_offset(o, g, tb);
+    const int oOl = mfma_elem_offset(e - s + 1, g, tb);
     double A = ident, Ol = 0.0, OrT = 0.0, Ro = 0.0, Y = 0.0, yo = 0.0;
     if (act) {
-      A = t.R[mfma_elem_offset(e, r, c)];
-      Ol = t.Oc[mfma_elem_offset(e - s + 1, r, c)];
-      OrT = t.Oc[mfma_elem_offset(e + 1, c, r)];
-      Ro = t.R[mfma_elem_offset(o, r, c)];
-      if (c == 0) { Y = t.y[e * 4 + r]; yo = t.y[o * 4 + r]; }
+      A = t.R[oRe];
+      Ol = t.Oc[oOl];
+      OrT = t.Oc[mfma_elem_offset(e + 1, gT, tT)];
+      Ro = t.R[oRo];
+      Y = t.y[e * 4 + r];
+      yo = t.y[o * 4 + r];
     }
     if (pend_e) {
-      A -= t.R[mfma_elem_offset(e + h, r, c)];
-      if (c == 0) Y -= t.y[(e + h) * 4 + r];
+      A -= t.R[mfma_elem_offset(e + h, g, tb)];
+      Y -= t.y[(e + h) * 4 + r];
     }
     if (pend_o) {
-      Ro -= t.R[mfma_elem_offset(o + h, r, c)];
-      if (c == 0) yo -= t.y[(o + h) * 4 + r];
+      Ro -= t.R[mfma_elem_offset(o + h, g, tb)];
+      yo -= t.y[(o + h) * 4 + r];
     }
+    Y = c0 ? Y : 0.0;
     // (every writer of a row or of a parked update stores the full symmetric block, so A and Ro
     // are symmetric as loaded)
     // ---- Li = L^-1 of A = L L^T, right-looking over the 16 lanes ------------------------------
@@ -113,18 +122,18 @@ __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K,
     const double FGt = mfma444(Ft, Gt, 0.0);                      // F G^T
     // ---- results (disjoint slots per elimination: no barrier between reads and writes) -----------
     if (act) {
-      t.R[mfma_elem_offset(e, r, c)] = GGt;
-      t.R[mfma_elem_offset(o, r, c)] = Ro - FFt;
-      t.Oc[mfma_elem_offset(e - s + 1, r, c)] = -FGt;
-      if (c == 0) {
-        t.y[e * 4 + r] = Gx;
-        t.y[o * 4 + r] = yo - Fx;
-        mah += X * X;
-        if (r == 0) {
-          pl.mul(piv);
-          fail = fail || f;
-        }
-      }
+      t.R[oRe] = GGt;
+      t.R[oRo] = Ro - FFt;
+      t.Oc[oOl] = -FGt;
+    }
+    if (act && c0) {
+      t.y[e * 4 + r] = Gx;
+      t.y[o * 4 + r] = yo - Fx;
+      mah += X * X;
+    }
+    if (act && c0 && r == 0) {
+      pl.mul(piv);
+      fail = fail || f;
     }
   }
   __syncthreads();
