@@ -670,7 +670,17 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   int64_t frow = (wb + rc) * rows_per_record;
   frow = (frow < N ? frow : N) - 1;
   if constexpr (!FINAL) {
-    write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial_out, sm.red, sm.sfail);
+    double logp = pl.value();
+    int fcode = fail ? (int)(frow + 1) : 0;
+    if (partial_in != nullptr) {           // last launch of a shard: fold in the partial results of the earlier ones
+      for (int64_t i = tid; i < n_partial; i += NT) {
+        const double* p = partial_in + pstride * i;
+        mah += p[0];
+        logp += p[1];
+        if (p[2] != 0.0 && (fcode == 0 || (int)p[2] < fcode)) fcode = (int)p[2];
+      }
+    }
+    write_partial<NT>(mah, logp, fcode, partial_out, sm.red, sm.sfail);
   } else {
     if (tid == 0) {                        // the very last row of the whole system
       T A[D][D], x[D];
@@ -845,17 +855,23 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     if (rc > Cfg::RCMAX) rc = Cfg::RCMAX;
     const int64_t per = (int64_t)Cfg::NTILE3 * rc;
     const int64_t g = (n + per - 1) / per;
+    const bool shard_last = shard_record && g == 1;
+    // the shard's single record and the sum of all partial results go straight to the caller
+    if (shard_last) rout = shard_record;
     hipLaunchKernelGGL((record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>), dim3((unsigned)g), dim3(Cfg::NT3),
-                       lds3, st, (const T*)rin, n, rc, rout, partial + PARTIAL_STRIDE * npart, (const double*)nullptr,
-                       (int64_t)0, (double*)nullptr, (int*)nullptr, rows_per_record, N, (int64_t)RL::STRIDE,
+                       lds3, st, (const T*)rin, n, rc, rout, shard_last ? shard_partial : partial + PARTIAL_STRIDE * npart,
+                       shard_last ? (const double*)partial : (const double*)nullptr, shard_last ? npart : (int64_t)0,
+                       (double*)nullptr, (int*)nullptr, rows_per_record, N, (int64_t)RL::STRIDE,
                        (int64_t)PARTIAL_STRIDE);
+    if (shard_last) return 0;
     npart += g;
     n = g;
     rows_per_record *= per;
     T* tmp = rin; rin = rout; rout = tmp;
   }
   if (shard_record) {
-    (void)hipMemcpyAsync(shard_record, rin, RL::STRIDE * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (rin != shard_record)                              // a shard of a single stage-1 tile: its record is still in the workspace
+      (void)hipMemcpyAsync(shard_record, rin, RL::STRIDE * sizeof(T), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(sum_partials4_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, npart, shard_partial);
     return 0;
   }
