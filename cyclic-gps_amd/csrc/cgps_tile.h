@@ -568,9 +568,31 @@ __global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_k
   set_zero<T, D>(Rc);
   set_zero<T, D>(yc);
   set_zero<T, D>(Cc);
+  // The right-hand side of YR = 4 consecutive rows of a 4 x 4 fp64 system shares one 128-byte
+  // line that a lane consumes over four steps (~13 us): by then L1 and L2 have dropped it and it
+  // is fetched again (PMC: 1.15 x the algorithmic bytes leave L2 that way).  Such lanes copy the
+  // whole line into their 128 bytes of the (still idle) LDS tile when they reach it.
+  constexpr int YR = 4;
+  constexpr bool YSTAGE = std::is_same<T, double>::value && D == 4 && C >= YR && C % YR == 0;
+  T* ylds = reinterpret_cast<T*>(smem) + (size_t)tid * (YR * D);
+  const bool yfull = YSTAGE && (r0 + C <= N);              // the lane's chunk is complete: whole lines exist
+  auto stage_y_line = [&](int64_t row) {                   // rows row .. row+YR-1 -> this lane's LDS line
+    if constexpr (YSTAGE) {
+      using V = typename Vec16<T>::type;
+      const V* src = reinterpret_cast<const V*>(yg + row * D);
+      V* dst = reinterpret_cast<V*>(ylds);
+#pragma unroll
+      for (int g = 0; g < YR * D / Vec16<T>::N; ++g) dst[g] = src[g];
+    }
+  };
   if (r0 < N) {
     load_block<T, D>(Rg + r0 * DD, Rc);
-    load_vec<T, D>(yg + r0 * D, yc);
+    if (yfull) {
+      stage_y_line(r0);
+      load_vec<T, D>(ylds, yc);
+    } else {
+      load_vec<T, D>(yg + r0 * D, yc);
+    }
     if (r0 >= 1) load_block<T, D>(Og + (r0 - 1) * DD, Cc);
     else if (Oleft != nullptr) load_block<T, D>(Oleft, Cc);
   }
@@ -581,9 +603,16 @@ __global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_k
     T Rn[D][D], On[D][D], yn[D];
     load_block<T, D>(Rg + rn * DD, Rn);
     load_block<T, D>(Og + (rn - 1) * DD, On);
-    load_vec<T, D>(yg + rn * D, yn);
+    if (yfull) {
+      if (((j + 1) & (YR - 1)) == 0) stage_y_line(rn);
+      load_vec<T, D>(ylds + ((j + 1) & (YR - 1)) * D, yn);
+    } else {
+      load_vec<T, D>(yg + rn * D, yn);
+    }
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
+  // (the tile is written only after the workgroup-wide barrier inside reduce_tile_and_emit: no lane
+  // is still reading its y line then)
 
   int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
   const int n_real = nreal64 > NT ? NT : (int)nreal64;
