@@ -232,10 +232,9 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 #endif
 
 #include "cgps_tile_mfma.h"
-// a level goes to the 16-lanes-per-elimination form when it has at most this many eliminations
-// (one pass of four waves; measured: 1.2 us against 2.2-2.6 us for a role-split pass, while two
-// such passes, or one with eight waves, are no faster than the role-split form)
-constexpr int MFMA_LEVEL_MAX_ELIMS = 16;
+// A level goes to the 16-lanes-per-elimination form when one pass of the workgroup's waves covers
+// it (16 eliminations for 256 threads, 32 for 512): measured 0.9-1.2 us against 1.9-2.6 us for a
+// role-split pass, while two such passes are no faster than one role-split pass.
 
 template <typename T, int D, int NTHR>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
@@ -256,7 +255,7 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
     const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
     if constexpr (std::is_same<T, double>::value && D == 4) {
       // narrow level: sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h)
-      if (n_elim <= MFMA_LEVEL_MAX_ELIMS) {
+      if (n_elim <= NTHR / 16) {
         tile_cr_level_mfma<NTHR>(t, K, M, s, pl, mah, fail);
         continue;
       }
@@ -543,8 +542,12 @@ struct StageSmem {
 template <typename T, int D> constexpr int stage1_min_waves() {
   return ((sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5)) ? 2 : 1;
 }
-template <typename T, int D, int C, int NT>
-__global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
+// NT lanes stream (one chunk each); NW >= NT threads run the workgroup.  NW = 2 NT is for grids of
+// at most one workgroup per CU: the extra four waves stream nothing, they are a second set of
+// role waves, so that the 128 eliminations of the tile's first level take one pass instead of two
+// (and the 32 of its third go to the matrix cores).
+template <typename T, int D, int C, int NT, int NW = NT>
+__global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
                                                           const T* __restrict__ Oleft,
                                                           T* __restrict__ rec, double* __restrict__ partial) {
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_k
   // first row of the whole system.
   constexpr int DD = D * D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  StageSmem<T, D, NT, NT> sm(smem);
+  StageSmem<T, D, NT, NW> sm(smem);
   const int tid = threadIdx.x;
   if (tid == 0) *sm.sfail = 0x7fffffff;
   const int64_t lane0 = (int64_t)blockIdx.x * NT;
-  const int64_t r0 = (lane0 + tid) * C;
+  const int64_t r0 = tid < NT ? (lane0 + tid) * C : N;          // threads past the lanes hold no rows
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
@@ -616,9 +619,9 @@ __global__ __launch_bounds__(NT, (stage1_min_waves<T, D>())) void chunk_reduce_k
 
   int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
   const int n_real = nreal64 > NT ? NT : (int)nreal64;
-  reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec, pl, mah, fail);
+  reduce_tile_and_emit<T, D, NW>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec, pl, mah, fail);
   int64_t frow = r0 < N ? r0 : N - 1;
-  write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial, sm.red, sm.sfail);
+  write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial, sm.red, sm.sfail);
 }
 
 // ---- stage 3 -----------------------------------------------------------------------------
@@ -821,6 +824,10 @@ void tile_set_attributes() {
   else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    if constexpr (stage1_min_waves<T, D>() == 2)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 8, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 4, Cfg::NT1>),
@@ -871,9 +878,21 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   else if (csel == 8)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 8, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                        Rs, Os, x, N, Oleft, recA, partial);
-  else
-    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial);
+  else {
+    bool wide = false;
+    if constexpr (stage1_min_waves<T, D>() == 2) {
+      // at most one workgroup per CU: give each a second set of role waves for its LDS reduction
+      if (tiles <= STAGE1_SMALL_TILES) {
+        wide = true;
+        const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
+                           dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial);
+      }
+    }
+    if (!wide)
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                         Rs, Os, x, N, Oleft, recA, partial);
+  }
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;
   T *rin = recA, *rout = recB;
