@@ -697,6 +697,18 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   }
   const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
   const int n_real = nthreads_real > NTILE ? NTILE : (int)nthreads_real;
+  // the partial results of the earlier launches: requested now, together with the records, and
+  // added at the end (another exposed memory latency otherwise)
+  double pre_mah = 0.0, pre_logp = 0.0;
+  int pre_fail = 0x7fffffff;
+  if (FINAL) {
+    for (int64_t i = tid; i < n_partial; i += NT) {
+      const double* p = partial_in + pstride * i;
+      pre_mah += p[0];
+      pre_logp += p[1];
+      if (p[2] != 0.0 && (int)p[2] < pre_fail) pre_fail = (int)p[2];
+    }
+  }
   reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah,
                                  fail);
   int64_t frow = (wb + rc) * rows_per_record;
@@ -725,15 +737,9 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
     }
     if (fail) atomicMin(sm.sfail, (int)(frow + 1));
-    double logp = pl.value();
-    int fmin = 0x7fffffff;
-    for (int64_t i = tid; i < n_partial; i += NT) {       // partial results of every earlier launch
-      const double* p = partial_in + pstride * i;
-      mah += p[0];
-      logp += p[1];
-      if (p[2] != 0.0 && (int)p[2] < fmin) fmin = (int)p[2];
-    }
-    if (fmin != 0x7fffffff) atomicMin(sm.sfail, fmin);
+    double logp = pl.value() + pre_logp;
+    mah += pre_mah;
+    if (pre_fail != 0x7fffffff) atomicMin(sm.sfail, pre_fail);
     block_sum2<NT>(mah, logp, sm.red);
     if (tid == 0) {
       out2[0] = mah;

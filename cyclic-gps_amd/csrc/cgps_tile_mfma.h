@@ -42,6 +42,8 @@ __device__ __forceinline__ double mfma444(double x, double y, double c) {  // X^
 
 // One level of the reduction (all its eliminations), then a barrier.  K = n_real - 1, M = rows of
 // this level, s = its stride (see tile_cr).  Every lane of the workgroup must call this.
+// (Letting wave 0 run the last levels -- at most four eliminations each -- without barriers was
+// measured: no gain.)
 template <int NTHR>
 __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K, int M, int s, PivotLog& pl, double& mah,
                                                    bool& fail) {
