@@ -64,27 +64,21 @@ __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K,
     const int o = (2 * k + 1 < M) ? e + s : K;
     const bool pend_e = act && (s > 1) && (e + h < K);
     const bool pend_o = act && (s > 1) && (o + h < K);
-    // ---- operands: one element per lane (y: every lane reads its row's entry, column 0 keeps it) --
-    const int oRe = mfma_elem_offset(e, g, tb), oRo = mfma_elem_offset(o, g, tb);
-    const int oOl = mfma_elem_offset(e - s + 1, g, tb);
-    double A = ident, Ol = 0.0, OrT = 0.0, Ro = 0.0, Y = 0.0, yo = 0.0;
-    if (act) {
-      A = t.R[oRe];
-      Ol = t.Oc[oOl];
-      OrT = t.Oc[mfma_elem_offset(e + 1, gT, tT)];
-      Ro = t.R[oRo];
-      Y = t.y[e * 4 + r];
-      yo = t.y[o * 4 + r];
-    }
-    if (pend_e) {
-      A -= t.R[mfma_elem_offset(e + h, g, tb)];
-      Y -= t.y[(e + h) * 4 + r];
-    }
-    if (pend_o) {
-      Ro -= t.R[mfma_elem_offset(o + h, g, tb)];
-      yo -= t.y[(o + h) * 4 + r];
-    }
-    Y = c0 ? Y : 0.0;
+    // ---- operands: one element per lane, branch-free (lanes without work read valid slots and
+    // discard; y: every lane reads its row's entry, column 0 keeps it) --------------------------
+    const int oRe = mfma_elem_offset(act ? e : K, g, tb), oRo = mfma_elem_offset(act ? o : K, g, tb);
+    const int oOl = mfma_elem_offset(act ? e - s + 1 : 0, g, tb);
+    const int ye = (act ? e : K) * 4 + r, yoff = (act ? o : K) * 4 + r;
+    const int pe = pend_e ? e + h : K, po = pend_o ? o + h : K;
+    const double lA = t.R[oRe], lOl = t.Oc[oOl], lOr = t.Oc[mfma_elem_offset(act ? e + 1 : 0, gT, tT)];
+    const double lRo = t.R[oRo], lY = t.y[ye], lyo = t.y[yoff];
+    const double pA = t.R[mfma_elem_offset(pe, g, tb)], pY = t.y[pe * 4 + r];
+    const double pR = t.R[mfma_elem_offset(po, g, tb)], py = t.y[po * 4 + r];
+    double A = act ? (pend_e ? lA - pA : lA) : ident;
+    const double Ol = act ? lOl : 0.0, OrT = act ? lOr : 0.0;
+    double Ro = pend_o ? lRo - pR : lRo;
+    double Y = (act && c0) ? (pend_e ? lY - pY : lY) : 0.0;
+    double yo = pend_o ? lyo - py : lyo;
     // (every writer of a row or of a parked update stores the full symmetric block, so A and Ro
     // are symmetric as loaded)
     // ---- Li = L^-1 of A = L L^T, right-looking over the 16 lanes ------------------------------
