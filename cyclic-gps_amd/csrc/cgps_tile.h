@@ -473,6 +473,9 @@ __device__ __forceinline__ void absorb_right_neighbour_update(T (&Rc)[D][D], T (
 // Common second half of both kernels: the lanes' kept rows -> LDS tile -> cyclic reduction ->
 // this tile's record (thread 0).  Lanes >= n_real carry nothing (zero updates, not stored).
 template <typename T, int D, int NT>
+__device__ __forceinline__ void reduce_staged_tile_and_emit(LdsTile<T, D>& t, int n_real, T* xch, T* __restrict__ rec_out,
+                                                            PivotLog& pl, double& mah, bool& fail);
+template <typename T, int D, int NT>
 __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D][D], T (&yc)[D], T (&Cc)[D][D],
                                                      T (&dRa)[D][D], T (&dya)[D], int n_real, T* xch,
                                                      T* __restrict__ rec_out, PivotLog& pl, double& mah, bool& fail) {
@@ -495,9 +498,21 @@ __device__ __forceinline__ void reduce_tile_and_emit(LdsTile<T, D>& t, T (&Rc)[D
       xch[D * D + i] = dya[i];
     }
   }
+  reduce_staged_tile_and_emit<T, D, NT>(t, n_real, xch, rec_out, pl, mah, fail);
+}
+
+// Second half: the rows are in the LDS tile (slot i = row i, Oc[i] = its coupling to row i-1, Oc[0]
+// to the row left of the tile) and xch holds the tile's own share for that row (lower triangle at
+// xch[i*D+j], vector at xch[D*D+i]).  Barrier, cyclic reduction, then thread 0 writes the record.
+template <typename T, int D, int NT>
+__device__ __forceinline__ void reduce_staged_tile_and_emit(LdsTile<T, D>& t, int n_real, T* xch, T* __restrict__ rec_out,
+                                                            PivotLog& pl, double& mah, bool& fail) {
+  using RL = RecordLayout<T, D>;
+  const int tid = threadIdx.x;
   __syncthreads();
   const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
   if (rec_out != nullptr && tid == 0) {
+    T dRa[D][D], dya[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
 #pragma unroll
@@ -679,6 +694,65 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
+  const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
+  const int n_real = nthreads_real > NTILE ? NTILE : (int)nthreads_real;
+  // the partial results of the earlier launches: requested now, together with the records, and
+  // added at the end (another exposed memory latency otherwise)
+  double pre_mah = 0.0, pre_logp = 0.0;
+  int pre_fail = 0x7fffffff;
+  if (FINAL) {
+    for (int64_t i = tid; i < n_partial; i += NT) {
+      const double* p = partial_in + pstride * i;
+      pre_mah += p[0];
+      pre_logp += p[1];
+      if (p[2] != 0.0 && (int)p[2] < pre_fail) pre_fail = (int)p[2];
+    }
+  }
+  constexpr int VN = Vec16<T>::N;
+  if ((D * D) % VN == 0 && rc == 1 && rstride % VN == 0) {
+    // One record per row: no sequential eliminations first, so the rows go straight into the LDS
+    // tile, all NT threads copying 16-byte granules (consecutive threads = consecutive granules of
+    // a record) instead of NTILE lanes walking one record each with 64 lines per instruction.
+    // Row w = Rs[w] + dRa[w+1], y = ys[w] + dya[w+1] (not for the tile's last row), coupling Cs[w].
+    using V = typename Vec16<T>::type;
+    using LT = LdsTile<T, D>;
+    constexpr int G = (D * D) / VN;
+    for (int gi = tid; gi < n_real * G; gi += NT) {
+      const int slot = gi / G, g = gi % G;
+      const int64_t w = w0 + slot;
+      const T* r = rin + (size_t)w * rstride;
+      V a = *reinterpret_cast<const V*>(r + RL::RS + g * VN);
+      const V c = *reinterpret_cast<const V*>(r + RL::CS + g * VN);
+      if (w != wlast) {
+        const V u = *reinterpret_cast<const V*>(r + rstride + RL::DRA + g * VN);
+        T* ae = reinterpret_cast<T*>(&a);
+        const T* ue = reinterpret_cast<const T*>(&u);
+#pragma unroll
+        for (int q = 0; q < VN; ++q) ae[q] += ue[q];
+      }
+      const int pg = LT::SWZ ? (g ^ LT::key(slot)) : g;
+      reinterpret_cast<V*>(sm.t.R + (size_t)slot * D * D)[pg] = a;
+      reinterpret_cast<V*>(sm.t.Oc + (size_t)slot * D * D)[pg] = c;
+    }
+    for (int vi = tid; vi < n_real * D; vi += NT) {
+      const int slot = vi / D, i = vi % D;
+      const int64_t w = w0 + slot;
+      const T* r = rin + (size_t)w * rstride;
+      T v = r[RL::YS + i];
+      if (w != wlast) v += r[rstride + RL::DYA + i];
+      sm.t.y[vi] = v;
+    }
+    if (tid == 0) {                                       // the tile's own share for the row left of it
+      const T* r = rin + (size_t)w0 * rstride;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) sm.xch[i * D + j] = r[RL::DRA + i * D + j];
+        sm.xch[D * D + i] = r[RL::DYA + i];
+      }
+    }
+    reduce_staged_tile_and_emit<T, D, NT>(sm.t, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah, fail);
+  } else {
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
   set_zero<T, D>(dya);
@@ -695,22 +769,9 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
     load_record_row<T, D>(rin, rstride, wb + j, n, wb + j != wlast, Rn, yn, On);
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
-  const int64_t nthreads_real = (n - w0 + rc - 1) / rc;
-  const int n_real = nthreads_real > NTILE ? NTILE : (int)nthreads_real;
-  // the partial results of the earlier launches: requested now, together with the records, and
-  // added at the end (another exposed memory latency otherwise)
-  double pre_mah = 0.0, pre_logp = 0.0;
-  int pre_fail = 0x7fffffff;
-  if (FINAL) {
-    for (int64_t i = tid; i < n_partial; i += NT) {
-      const double* p = partial_in + pstride * i;
-      pre_mah += p[0];
-      pre_logp += p[1];
-      if (p[2] != 0.0 && (int)p[2] < pre_fail) pre_fail = (int)p[2];
-    }
-  }
   reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah,
                                  fail);
+  }
   int64_t frow = (wb + rc) * rows_per_record;
   frow = (frow < N ? frow : N) - 1;
   if constexpr (!FINAL) {
