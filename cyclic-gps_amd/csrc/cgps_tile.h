@@ -511,26 +511,32 @@ __device__ __forceinline__ void reduce_staged_tile_and_emit(LdsTile<T, D>& t, in
   const int tid = threadIdx.x;
   __syncthreads();
   const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
-  if (rec_out != nullptr && tid == 0) {
-    T dRa[D][D], dya[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-#pragma unroll
-      for (int j = 0; j <= i; ++j) dRa[i][j] = xch[i * D + j];
-      dya[i] = xch[D * D + i];
+  // the record, one block element per lane (every parked block is stored symmetric): D*D lanes of
+  // wave 0 instead of thread 0 walking the levels one after the other
+  if (rec_out != nullptr && tid < D * D) {
+    using LT = LdsTile<T, D>;
+    constexpr int VN = LT::VN;
+    const int i = tid / D, j = tid % D;
+    auto elem = [&](const T* base, int slot) {
+      const int idx = i * D + j;
+      const T* p = base + (size_t)slot * D * D;
+      return LT::SWZ ? p[((idx / VN) ^ LT::key(slot)) * VN + (idx % VN)] : p[idx];
+    };
+    T dra = (i >= j) ? xch[i * D + j] : xch[j * D + i];
+    T dyv = xch[D * D + i];
+    for (int l = 0; l < levels; ++l) {
+      const int slot = (1 << l) - 1;
+      dra -= elem(t.R, slot);
+      dyv -= t.y[slot * D + i];
     }
-    collect_left_updates<T, D>(t, levels, dRa, dya);
-    T Rs_[D][D], ys_[D], Cs_[D][D];
-    LdsTile<T, D>::load_blk(t.R, n_real - 1, Rs_);
-    load_vec<T, D>(t.y + (n_real - 1) * D, ys_);
-    LdsTile<T, D>::load_blk(t.Oc, 0, Cs_);
     T* r = rec_out + (size_t)blockIdx.x * RL::STRIDE;
-    store_block<T, D>(r + RL::RS, Rs_);
-    store_block<T, D>(r + RL::CS, Cs_);
-    mirror_lower<T, D>(dRa);
-    store_block<T, D>(r + RL::DRA, dRa);
-    store_vec<T, D>(r + RL::YS, ys_);
-    store_vec<T, D>(r + RL::DYA, dya);
+    r[RL::RS + tid] = elem(t.R, n_real - 1);
+    r[RL::CS + tid] = elem(t.Oc, 0);
+    r[RL::DRA + tid] = dra;
+    if (j == 0) {
+      r[RL::YS + i] = t.y[(n_real - 1) * D + i];
+      r[RL::DYA + i] = dyv;
+    }
   }
 }
 
