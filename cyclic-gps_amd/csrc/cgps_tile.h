@@ -7,8 +7,8 @@
 // decompose keeps the reference's even/odd order, its factors being API output):
 //
 //  stage 1, chunk_reduce_kernel: the time axis is cut into chunks of C block
-//    rows, one chunk per lane.  A lane streams its rows from HBM (16-byte loads,
-//    the next row is in flight while the current one is eliminated) and
+//    rows, one chunk per lane.  A lane streams its rows from HBM (16-byte loads;
+//    the right-hand-side line it shares with its next rows goes through LDS) and
 //    eliminates rows c0 .. c0+C-2 left to right in registers.  The Schur
 //    complement of the chunk interior lands on its two boundary rows: the
 //    chunk's own last row (kept: R_s, y_s and C_s = its new coupling to the
@@ -21,6 +21,8 @@
 //    ~8 cycles), so one elimination's ~480 fp64 instructions are split over FOUR
 //    waves by role (left-neighbour products / right-neighbour update / two halves
 //    of the new coupling block): the operands are in LDS anyway, no shuffles.
+//    Levels with few eliminations (4 x 4 fp64 blocks) run on the matrix cores
+//    instead, sixteen lanes per elimination: cgps_tile_mfma.h.
 //  stage 3, record_reduce_kernel: records are rows of a (N / (C NT))-row system;
 //    the same tile_cr reduces them (recursively for very large N) and the last
 //    launch eliminates the final row, sums the partial log-det / mahal in a
