@@ -1,0 +1,79 @@
+"""Randomised closed-form parity sweep on the GPU (no oracle needed: J = L L^T with L block
+bidiagonal, so log|J| and the planted solution are known exactly -- tests/_util.conditioned_system).
+
+Sizes are drawn around every switch point of the kernels (rows per lane 1 / 4 / 8 / 16, one or
+two workgroups per CU, record passes, decompose / solve pass structures) and uniformly in between.
+
+  python tools/fuzz_parity.py --seconds 120 [--seed 0]
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import _util  # noqa: E402
+import cyclic_gps.cyclic_reduction as cr  # noqa: E402
+
+EDGES = [1, 2, 3, 64, 128, 129, 255, 256, 257, 1024, 4096, 4097, 16384, 32768, 32769, 65536, 65537, 131072,
+         262144, 262145, 524288, 524289, 1048576, 1048577, 1 << 21, (1 << 21) + 1]
+
+
+def draw_n(rng, cap):
+    r = rng.random()
+    if r < 0.5:
+        e = rng.choice(EDGES)
+        n = e + rng.choice([-3, -2, -1, 0, 0, 1, 2, 3, 17, -17, 255, -255])
+    elif r < 0.8:
+        n = int(2 ** rng.uniform(0, 20.5))
+    else:
+        n = rng.randrange(1, 5000)
+    return max(1, min(n, cap))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = random.Random(a.seed)
+    t0 = time.time()
+    cases = worst64 = worst32 = 0
+    while time.time() - t0 < a.seconds:
+        d = rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 7, 8])
+        dtype = rng.choice([torch.float64, torch.float64, torch.float32])
+        n = draw_n(rng, (1 << 21) + 300 if d <= 4 else (1 << 19) + 300)
+        Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=rng.randrange(1 << 30))
+        mahal_true = float((x_true.double() * b.double()).sum())
+        tol = 1e-9 if dtype == torch.float64 else 3e-4
+        tag = "n=%d d=%d %s" % (n, d, "f64" if dtype == torch.float64 else "f32")
+        m, ld = cr.mahal_and_det(Rs, Os, b)
+        e1 = abs(float(ld) - logdet) / max(1.0, abs(logdet))
+        e2 = abs(float(m) - mahal_true) / max(1.0, abs(mahal_true))
+        dec = cr.decompose(Rs, Os)
+        x = cr.solve(dec, b)
+        e3 = float((x.double() - x_true.double()).abs().max())
+        e4 = abs(float(cr.det(dec)) - logdet) / max(1.0, abs(logdet))
+        err = max(e1, e2 / 10, e3 / 10, e4)
+        if not err <= tol:
+            print("FAIL", tag, "logdet %.3e mahal %.3e solve %.3e det %.3e" % (e1, e2, e3, e4), flush=True)
+            sys.exit(1)
+        if dtype == torch.float64:
+            worst64 = max(worst64, err)
+        else:
+            worst32 = max(worst32, err)
+        cases += 1
+        if cases % 50 == 0:
+            print("%d cases, worst fp64 %.2e fp32 %.2e, last %s" % (cases, worst64, worst32, tag), flush=True)
+    print("OK: %d cases in %.0f s, worst fp64 %.2e, worst fp32 %.2e" % (cases, time.time() - t0, worst64, worst32))
+
+
+if __name__ == "__main__":
+    main()
