@@ -811,10 +811,14 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
     if (pre_fail != 0x7fffffff) atomicMin(sm.sfail, pre_fail);
     block_sum2<NT>(mah, logp, sm.red);
     if (tid == 0) {
-      out2[0] = mah;
-      out2[1] = logp;
       const int f = *sm.sfail;
-      *info = (f == 0x7fffffff) ? 0 : f;
+      const bool ok = (f == 0x7fffffff);
+      // a caller that does not read `info` must not get a plausible number out of a system that is
+      // not positive definite (two negative pivots multiply to a positive "determinant")
+      const double poison = __builtin_nan("");
+      out2[0] = ok ? mah : poison;
+      out2[1] = ok ? logp : poison;
+      *info = ok ? 0 : f;
     }
   }
 }

@@ -32,7 +32,9 @@ except Exception:  # pragma: no cover
         """A diagonal block was not positive definite."""
 
 # Set to False to skip the device->host read of the `info` word after a
-# factorisation (removes one stream synchronisation per call).
+# factorisation (removes one stream synchronisation per call).  Nothing raises then:
+# mahal_and_det returns NaN for both scalars on a block that is not positive definite, and a
+# factor carries the NaNs of the failed square root.
 CHECK_POSITIVE_DEFINITE = True
 
 

@@ -74,7 +74,9 @@ int cgps_level_layout(int64_t N, int* nlevels, int64_t* ms, int64_t* offD, int64
 int cgps_workspace_bytes(int64_t N, int d, int dtype, int op, size_t* bytes);
 
 /* mahal_and_det(Rs, Os, x) -> (x^T J^-1 x, log|J|)        cyclic_reduction.py:380-438
- * out2[0] = mahal, out2[1] = logdet (device doubles, accumulated in fp64 for both dtypes). */
+ * out2[0] = mahal, out2[1] = logdet (device doubles, accumulated in fp64 for both dtypes).
+ * When a block is not positive definite (info != 0) cgps_mahal_logdet and cgps_finish_records
+ * write NaN to both, so a caller that never reads info cannot take a wrong number for a result. */
 int cgps_mahal_logdet(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype,
                       void* ws, size_t ws_bytes, double* out2, int* info, void* stream);
 /* same result, one kernel launch per reduction level (simple form, kept as cross-check) */

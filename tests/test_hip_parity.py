@@ -140,6 +140,17 @@ def test_not_positive_definite_raises():
     Rs[17] = float("nan")
     with pytest.raises(cr.NotPSDError):
         cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
+    # without the host-side check (no device sync) the results are poisoned, never plausible:
+    # two negative pivots multiply to a positive "determinant"
+    Rs, Os, b, _, _ = _util.conditioned_system(5000, 4)
+    Rs[100] = -Rs[100]
+    Rs[3000] = -Rs[3000]
+    cr.CHECK_POSITIVE_DEFINITE = False
+    try:
+        m, ld = cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
+    finally:
+        cr.CHECK_POSITIVE_DEFINITE = True
+    assert torch.isnan(m) and torch.isnan(ld)
 
 
 @pytest.mark.parametrize("N,d,dtype,rtol", [
