@@ -128,7 +128,7 @@ __device__ __forceinline__ void store_blocks_coalesced(T* stage, T* __restrict__
 // nothing is left; otherwise lv.nlev <= 7 levels, then the surviving rows go to rec_out
 // (tile t, survivor m -> record t * (DEC_TS >> lv.nlev) + m; a tile's first record also carries DRA).
 template <typename T, int D, bool FROM_RECORDS>
-__global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict__ Rin, const T* __restrict__ Oin,
+__global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_tile_kernel(const T* __restrict__ Rin, const T* __restrict__ Oin,
                                                              int64_t n, int64_t n_rec, int spt_in, DecompLevels lv,
                                                              int lvl_first,
                                                              T* __restrict__ Dp, T* __restrict__ Fp,
@@ -162,16 +162,14 @@ __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict
       }
     }
   };
-  // rows 2k (Re, its coupling Cl to row 2k-1) and 2k+1 (Ro, its coupling Cm to row 2k) of a tile
-  auto fetch = [&](int64_t tile, T (&Re)[D][D], T (&Cl)[D][D], T (&Ro)[D][D], T (&Cm)[D][D]) {
+  auto process = [&](int64_t tile) {
     const int64_t row0 = tile * DEC_TS;
-    const int64_t w = row0 + 2 * lane;
-    if (w < n) load_row(w, Re, Cl);
-    if (w + 1 < n) load_row(w + 1, Ro, Cm);
-  };
-
-  auto process = [&](int64_t tile, T (&Re)[D][D], T (&Cl)[D][D], T (&Rr)[D][D], T (&Cm)[D][D]) {
-    const int64_t row0 = tile * DEC_TS;
+    // The even row now, the odd row only once the even row's D and G are out: with all four
+    // blocks loaded up front the kernel needs 330 registers (one wave per SIMD, every latency of
+    // the wave exposed); this way 238, two waves per SIMD cover each other (first pass 156 -> 132 us).
+    T Re[D][D], Cl[D][D], Rr[D][D], Cm[D][D];
+    set_zero<T, D>(Re); set_zero<T, D>(Cl); set_zero<T, D>(Rr); set_zero<T, D>(Cm);   // lanes past the end of a
+    if (row0 + 2 * lane < n) load_row(row0 + 2 * lane, Re, Cl);                       // ragged tile load nothing
     const int n0 = (int)((n - row0) < DEC_TS ? (n - row0) : DEC_TS);
     auto report = [&](int slot_row) { report_fail(info, ((row0 + slot_row + 1) << lvl_first) - 1); };
     T Cc[D][D];                    // coupling of the row this lane carries (Rr) to the previous such row
@@ -205,6 +203,7 @@ __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict
         syrk_lower<T, D>(UL, G);                                   // owed to row 2k-1
       }
       store_blocks_coalesced<T, D>(stage, Gp + (lv.offG[0] + ge0 - 1) * DD, G, act, lane, cntD, ge0 == 0 ? 1 : 0);
+      if (has_o) load_row(row0 + 2 * lane + 1, Rr, Cm);
       {
         T U[D][D];
         shfl_lower<T, D>(U, UL, lane + 1);                         // what row 2k+2 owes row 2k+1
@@ -305,15 +304,10 @@ __global__ __launch_bounds__(DEC_NT) void decomp_tile_kernel(const T* __restrict
   };
 
   // persistent wave: tiles blockIdx.x, + gridDim.x, ...  (a second register buffer that keeps the
-  // next tile's rows in flight was tried and is slower: the compiler's conservative vmcnt(0)
-  // waits around the stores drain the prefetch anyway, and it costs the registers)
-  T A0[D][D], A1[D][D], A2[D][D], A3[D][D];
-  set_zero<T, D>(A0); set_zero<T, D>(A1); set_zero<T, D>(A2); set_zero<T, D>(A3);   // lanes past the end of a
-#pragma unroll 1                                                                     // ragged tile fetch nothing
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    fetch(tile, A0, A1, A2, A3);
-    process(tile, A0, A1, A2, A3);
-  }
+  // next tile's rows in flight was tried and is slower: it costs the registers that a second
+  // wave per SIMD needs, and that second wave is what hides the latencies)
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) process(tile);
 }
 
 }  // namespace cgps
