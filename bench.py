@@ -77,6 +77,44 @@ def _time_cuda(fn, reps, warm=2):
     return (time.perf_counter() - t0) / reps
 
 
+def two_systems_in_flight(dev, rows, d, dtype, steps):
+    """Information only (never `value`): throughput when TWO independent systems are solved on two
+    HIP streams, so that the serial tail of one (LDS levels, final workgroup: HBM idle) overlaps the
+    streaming of the other.  Same library calls, separate workspaces and outputs per stream."""
+    from cyclic_gps import _hip
+    lib = _hip.lib()
+    dcode = _hip.dtype_code(dtype)
+    systems = []
+    for i in range(2):
+        Rs, Os, b, _, logdet_true = make_system(rows, d, dtype, dev, seed=1234 + i)
+        ws, ws_bytes = _hip.workspace(rows + 1 + i, d, dtype, _hip.OP_MAHAL_LOGDET, dev)
+        ws = ws.clone()                      # the cache may hand the same buffer twice
+        systems.append(dict(Rs=Rs, Os=Os, b=b, ws=ws, ws_bytes=ws.numel() * ws.element_size(), logdet=logdet_true,
+                            out=torch.zeros(2, dtype=torch.float64, device=dev),
+                            info=torch.zeros(1, dtype=torch.int32, device=dev), stream=torch.cuda.Stream(device=dev)))
+
+    def launch(s):
+        _hip.check(lib.cgps_mahal_logdet(_hip.ptr(s["Rs"]), _hip.ptr(s["Os"]), _hip.ptr(s["b"]), rows, d, dcode,
+                                         _hip.ptr(s["ws"]), s["ws_bytes"], _hip.ptr(s["out"]), _hip.ptr(s["info"]),
+                                         ctypes.c_void_p(s["stream"].cuda_stream)))
+    torch.cuda.synchronize()
+    for _ in range(10):
+        for s in systems:
+            launch(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for s in systems:
+            launch(s)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / (2 * steps)
+    errs = [abs(float(s["out"][1]) - s["logdet"]) / abs(s["logdet"]) for s in systems]
+    sz = 8 if dtype == torch.float64 else 4
+    return {"us_per_solve": t * 1e6, "GBps": algorithmic_bytes(rows, d, sz) / t / 1e9,
+            "frac_of_8TBps": algorithmic_bytes(rows, d, sz) / t / 1e9 / HBM_PEAK_GBPS, "logdet_rel_err_max": max(errs),
+            "note": "two independent systems on two streams; the headline `value` is one system, one stream"}
+
+
 def extra_measurements(dev):
     """Secondary numbers of SURVEY.md 8(d), outside the timed region of the headline metric:
     Op B (decompose + solve + det through the module surface, N=2^20 d=4 fp64), BASELINE
@@ -133,6 +171,10 @@ def extra_measurements(dev):
         }
     except Exception as e:
         out["c1_N1024_d2_f64"] = {"error": repr(e)[:200]}
+    try:
+        out["opA_two_systems_in_flight_N2^20_d4_f64"] = two_systems_in_flight(dev, 1 << 20, 4, torch.float64, 200)
+    except Exception as e:
+        out["opA_two_systems_in_flight_N2^20_d4_f64"] = {"error": repr(e)[:200]}
     cr.CHECK_POSITIVE_DEFINITE = True
     # BASELINE config 5: LEG log-likelihood + posterior mean on the CO2-shaped series (N=502, rank 5),
     # parameters and expected values from the fixture recorded from the reference
