@@ -352,6 +352,15 @@ def main():
         if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise:
             line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json"
+            # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats
+            # summary of this command (HIP events around a launch also see its dispatch latency)
+            import csv
+            prof = "profiles/r01_kernel_stats_headline_v9.csv"
+            for r in csv.DictReader(open(os.path.join(ROOT, prof))):
+                if "chunk_reduce_kernel" in r["Name"]:
+                    line["roofline"]["kernel_avg_us_rocprofv3"] = float(r["AverageNs"]) / 1e3
+                    line["roofline"]["kernel_avg_us_rocprofv3_source"] = prof
+                    break
     except Exception:
         pass
     if not sharded_mode and not args.no_extras:
