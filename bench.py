@@ -26,7 +26,11 @@ import os
 import sys
 import time
 
-import torch
+# RCCL / CUDA-tensor sharing across processes needs dmabuf IPC on this pool (already exported on
+# the GPU boxes; set before HIP initialises in case a launcher dropped it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests")):
