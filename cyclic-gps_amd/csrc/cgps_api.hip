@@ -13,6 +13,7 @@
 #include "cgps_solve_tile.h"
 #include "cgps_decomp_tile.h"
 #include "cgps_decomp_lds.h"
+#include "cgps_inverse_tile.h"
 #include "cgps_leg.h"
 #include <cstdlib>
 
@@ -350,6 +351,7 @@ int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, co
   return check_launch("backsolve");
 }
 
+constexpr int64_t INV_FUSED_MIN_ROWS = 1024;   // a fused inverse pass must produce at least this many rows
 template <typename T, int D>
 int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, char* ws, size_t ws_bytes,
                 hipStream_t st) {
@@ -360,13 +362,47 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   make_layout(N, L);
   T* bufs[2] = {reinterpret_cast<T*>(ws), reinterpret_cast<T*>(ws + one)};
   const T *Sdc = nullptr, *Soc = nullptr;
-  for (int l = L.nlevels - 1; l >= 0; --l) {
+  // The coarse levels one launch each (latency-bound, little data); once a level that is a
+  // multiple of INV_LP above level 0 is reached and the rows get many, INV_LP levels per launch
+  // (cgps_inverse_tile.h): those passes read 1/8 of what they write instead of ping-ponging every
+  // level's Sigma through HBM.
+  constexpr bool FUSED = (size_t)D * D * sizeof(T) <= 128;
+  const size_t lds = (size_t)64 * D * D * sizeof(T);
+  static int grid_cap = 0;
+  if (FUSED && grid_cap == 0) {
+    int dev = 0, cus = 256, nb = 2;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cgps::inverse_tile_kernel<T, D>, cgps::INV_NT, lds);
+    grid_cap = cus * (nb > 0 ? nb : 1);
+  }
+  int p = 0;
+  for (int l = L.nlevels - 1; l >= 0;) {
+    const int have = l + 1;                               // Sdc / Soc hold Sigma of this level
+    if (FUSED && Sdc != nullptr && have % cgps::INV_LP == 0 && L.ms[have] >= 1 &&
+        L.ms[have - cgps::INV_LP] >= INV_FUSED_MIN_ROWS) {
+      const int lf = have - cgps::INV_LP;
+      const int64_t n = L.ms[lf], tiles = (n + cgps::INV_TS - 1) / cgps::INV_TS;
+      cgps::InverseLevels lv;
+      for (int t = 0; t < cgps::INV_LP; ++t) {
+        lv.offD[t] = L.offD[lf + t]; lv.offF[t] = L.offF[lf + t]; lv.offG[t] = L.offG[lf + t];
+      }
+      T* od = (lf == 0) ? Sd : bufs[p];
+      T* oo = (lf == 0) ? So : bufs[p] + cap * D * D;
+      const int64_t grid = tiles < grid_cap ? tiles : grid_cap;
+      hipLaunchKernelGGL((cgps::inverse_tile_kernel<T, D>), dim3((unsigned)grid), dim3(cgps::INV_NT), lds, st, Dp, Fp,
+                         Gp, lv, Sdc, Soc, n, od, oo);
+      Sdc = od; Soc = oo; p ^= 1;
+      l = lf - 1;
+      continue;
+    }
     const int64_t n = L.ms[l], nb = level_blocks(n);
-    T* od = (l == 0) ? Sd : bufs[l & 1];
-    T* oo = (l == 0) ? So : bufs[l & 1] + cap * D * D;
+    T* od = (l == 0) ? Sd : bufs[p];
+    T* oo = (l == 0) ? So : bufs[p] + cap * D * D;
     hipLaunchKernelGGL((cgps::inverse_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
                        Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D, Sdc, Soc, n, od, oo);
-    Sdc = od; Soc = oo;
+    Sdc = od; Soc = oo; p ^= 1;
+    --l;
   }
   return check_launch("inverse_blocks");
 }

@@ -1,0 +1,304 @@
+// Fused selected inverse (inverse_blocks, reference cyclic_reduction.py:470-503), coarse -> fine:
+// INV_LP = 3 levels of the recurrence per launch instead of one.
+//
+// Same shape as cgps_decomp_tile.h run backwards: ONE WAVE per 128-row tile of the pass's finest
+// level, the tile's blocks of Sigma in REGISTERS, neighbours through wave shuffles.  Relative
+// level t = 3 is the input (16 rows per tile, read from the previous pass's output), t = 2, 1, 0
+// are computed; row m of level t >= 1 sits in lane (m+1) 2^(t-1) - 1, lane k of level 0 holds
+// rows 2k and 2k+1.  Every lane keeps, for the row it holds, Sigma[row,row] and
+// Sigma[row, previous row of the current level].
+// An even row 2k of a level needs Sigma of its two odd neighbours (lanes +-st) and their mutual
+// coupling (held by the right one), computes its own diagonal block and the two couplings to its
+// neighbours (inverse_even_row below = the level-wise kernel's algebra), keeps the left coupling
+// and hands the right one to the right neighbour.  A tile's first even row takes its left
+// neighbour -- the previous tile's last row, an odd row at every level of the pass, so its
+// Sigma block is the input level's -- from global memory.
+// The level-wise form reads and writes every level's Sigma once each way (2/3 of its traffic at
+// the fine levels is this ping-pong); here a pass reads 1/8 of what it writes.
+#pragma once
+#include "cgps_decomp_tile.h"
+#include "cgps_level.h"
+
+namespace cgps {
+
+constexpr int INV_LP = 3;
+constexpr int INV_TS = 128;
+constexpr int INV_NT = 64;
+
+struct InverseLevels {
+  int64_t offD[INV_LP], offF[INV_LP], offG[INV_LP];   // packed-array offsets of levels L, L+1, L+2
+};
+
+template <typename T, int D>
+__device__ __forceinline__ void set_identity(T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = (i == j) ? T(1) : T(0);
+}
+
+// Even row 2k of one level.  Dl = D_k (dense lower Cholesky factor), F = F_k (if has_odd),
+// G = G_k-1 (if has_left); SdR / SdL = Sigma~ of the right / left odd neighbour (coarse rows k and
+// k-1), SoR = Sigma~[k, k-1].  Out: See = Sigma[2k,2k], oR = Sigma[2k+1,2k], oL = Sigma[2k,2k-1].
+template <typename T, int D>
+__device__ __forceinline__ void inverse_even_row(const T (&Dl)[D][D], const T (&F)[D][D], const T (&G)[D][D],
+                                                 const T (&SdR)[D][D], const T (&SoR)[D][D], const T (&SdL)[D][D],
+                                                 bool has_odd, bool has_left, T (&See)[D][D], T (&oR)[D][D],
+                                                 T (&oL)[D][D]) {
+  // D^-1 is lower triangular and Sigma[2k,2k] symmetric: only those halves are computed
+  // (446 instead of 720 multiply-adds at d = 4; at one wave per SIMD the pass is bound by this chain).
+  T inv[D], Di[D][D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) inv[i] = rcp_fast(Dl[i][i]);
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (i < j) Di[i][j] = T(0);
+      else if (i == j) Di[i][j] = inv[i];
+      else {
+        T sacc = T(0);
+#pragma unroll
+        for (int m = j; m < i; ++m) sacc = fmaT(-Dl[i][m], Di[m][j], sacc);
+        Di[i][j] = sacc * inv[i];
+      }
+    }
+  }
+  set_zero<T, D>(oR);
+  set_zero<T, D>(oL);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {                       // lower(D^-T D^-1)
+      T sacc = T(0);
+#pragma unroll
+      for (int m = i; m < D; ++m) sacc = fmaT(Di[m][i], Di[m][j], sacc);
+      See[i][j] = sacc;
+    }
+  T Ak[D][D], Bk[D][D], M[D][D];
+  auto times_di = [&](T (&C)[D][D], const T (&X)[D][D]) {   // C = X D^-1
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        T sacc = T(0);
+#pragma unroll
+        for (int m = j; m < D; ++m) sacc = fmaT(X[i][m], Di[m][j], sacc);
+        C[i][j] = sacc;
+      }
+  };
+  auto acc_lower_tn = [&](const T (&X)[D][D], const T (&Y)[D][D]) {   // lower(See) += lower(X^T Y)
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        T sacc = See[i][j];
+#pragma unroll
+        for (int m = 0; m < D; ++m) sacc = fmaT(X[m][i], Y[m][j], sacc);
+        See[i][j] = sacc;
+      }
+  };
+  set_zero<T, D>(Ak);
+  set_zero<T, D>(Bk);
+  if (has_odd) times_di(Ak, F);                          // A_k = F_k D_k^-1
+  if (has_left) times_di(Bk, G);                         // B_k-1 = G_k-1 D_k^-1
+  if (has_odd) {
+    mm<T, D>(M, SdR, Ak);
+    if (has_left) mm_acc<T, D>(M, SoR, Bk);
+    acc_lower_tn(Ak, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) oR[i][j] = -M[i][j];
+  }
+  if (has_left) {
+    mm<T, D>(M, SdL, Bk);
+    if (has_odd) mm_tn_acc<T, D>(M, SoR, Ak);
+    acc_lower_tn(Bk, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) oL[i][j] = -M[j][i];
+  }
+  mirror_lower<T, D>(See);
+}
+
+// Lane k holds blocks 2k (A0, if has0) and 2k+1 (A1, if has1) of dst[cnt][D*D]; blocks below
+// `first` are not written.  Through LDS (`stage`: 64 blocks), half a wave's pairs at a time, so
+// that every store instruction writes 64 x 16 consecutive bytes (see store_blocks_coalesced).
+template <typename T, int D>
+__device__ __forceinline__ void store_pairs_coalesced(T* stage, T* __restrict__ dst, const T (&A0)[D][D], bool has0,
+                                                      const T (&A1)[D][D], bool has1, int cnt, int first) {
+  constexpr int DD = D * D, VN = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const int b0 = 64 * h;                                       // first block of this half
+    if (b0 >= cnt) break;
+    const bool mine = (lane >> 5) == h;
+    const int k = 2 * (lane & 31);
+    const int hi = (cnt - b0) < 64 ? (cnt - b0) : 64;
+    const int lo = first > b0 ? first - b0 : 0;
+    if constexpr (DD % VN == 0) {
+      using V = typename Vec16<T>::type;
+      constexpr int G = DD / VN;
+      constexpr bool SWZ = (G & (G - 1)) == 0 && G >= 2;
+      V* sv = reinterpret_cast<V*>(stage);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        V v0, v1;
+        T* e0 = reinterpret_cast<T*>(&v0);
+        T* e1 = reinterpret_cast<T*>(&v1);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) {
+          e0[t] = A0[(g * VN + t) / D][(g * VN + t) % D];
+          e1[t] = A1[(g * VN + t) / D][(g * VN + t) % D];
+        }
+        if (mine && has0) sv[k * G + (SWZ ? (g ^ (k & (G - 1))) : g)] = v0;
+        if (mine && has1) sv[(k + 1) * G + (SWZ ? (g ^ ((k + 1) & (G - 1))) : g)] = v1;
+      }
+      __builtin_amdgcn_wave_barrier();
+      V* dv = reinterpret_cast<V*>(dst) + (size_t)b0 * G;
+#pragma unroll 1
+      for (int v = lo * G + lane; v < hi * G; v += 64) {
+        const int kk = v / G, g = v % G;
+        dv[v] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      if (mine) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) {
+            if (has0) stage[k * DD + a * D + b] = A0[a][b];
+            if (has1) stage[(k + 1) * DD + a * D + b] = A1[a][b];
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      T* dd = dst + (size_t)b0 * DD;
+#pragma unroll 1
+      for (int v = lo * DD + lane; v < hi * DD; v += 64) dd[v] = stage[v];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// One pass: Sigma of level L+3 (Sd_in[n >> 3], So_in[(n >> 3) - 1]) -> Sigma of level L
+// (Sd_out[n], So_out[n-1]); n = rows of level L, n >> 3 >= 1.  Dp/Fp/Gp: the packed factor.
+template <typename T, int D>
+__global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restrict__ Dp, const T* __restrict__ Fp,
+                                                              const T* __restrict__ Gp, InverseLevels lv,
+                                                              const T* __restrict__ Sd_in, const T* __restrict__ So_in,
+                                                              int64_t n, T* __restrict__ Sd_out,
+                                                              T* __restrict__ So_out) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* stage = reinterpret_cast<T*>(smem);
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (n + INV_TS - 1) / INV_TS;
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * INV_TS;
+    const int n0 = (int)((n - row0) < INV_TS ? (n - row0) : INV_TS);
+    const int64_t g3 = row0 >> INV_LP;
+    const int n3 = n0 >> INV_LP;
+    T Sdv[D][D], Sov[D][D], SdLeft[D][D];
+    set_zero<T, D>(Sdv);
+    set_zero<T, D>(Sov);
+    set_zero<T, D>(SdLeft);
+    {
+      const int m = ((lane + 1) >> 2) - 1;
+      if (((lane + 1) & 3) == 0 && m < n3) {
+        load_block<T, D>(Sd_in + (g3 + m) * DD, Sdv);
+        if (g3 + m >= 1) load_block<T, D>(So_in + (g3 + m - 1) * DD, Sov);
+      }
+    }
+    if (row0 > 0) load_block<T, D>(Sd_in + (g3 - 1) * DD, SdLeft);
+
+    // The factor blocks of a level do not depend on Sigma: a level's D, F, G are requested one
+    // level ahead, so their HBM latency passes under the previous level's arithmetic (with one wave
+    // per SIMD nothing else hides it: 146 -> see DESIGN.md for the pass at N = 2^20).
+    auto geom = [&](int t, bool& even, bool& odd, bool& has_odd, bool& has_left, int& m, int64_t& kg) {
+      if (t == 0) {
+        even = 2 * lane < n0; odd = false; has_odd = 2 * lane + 1 < n0; m = 2 * lane;
+        kg = (row0 >> 1) + lane;
+      } else {
+        const int st = 1 << (t - 1);
+        const int M = n0 >> t;
+        m = ((lane + 1) >> (t - 1)) - 1;
+        const bool exists = (((lane + 1) & (st - 1)) == 0) && m < M;
+        even = exists && (m & 1) == 0; odd = exists && (m & 1) == 1;
+        kg = (row0 >> (t + 1)) + (m >> 1);
+        has_odd = even && (m + 1 < M);
+      }
+      has_left = even && kg >= 1;
+    };
+    auto load_factors = [&](int t, T (&Dl)[D][D], T (&F)[D][D], T (&G)[D][D]) {
+      bool even, odd, has_odd, has_left; int m; int64_t kg;
+      geom(t, even, odd, has_odd, has_left, m, kg);
+      set_zero<T, D>(F);
+      set_zero<T, D>(G);
+      if (even) load_block<T, D>(Dp + (lv.offD[t] + kg) * DD, Dl);
+      else set_identity<T, D>(Dl);
+      if (has_odd) load_block<T, D>(Fp + (lv.offF[t] + kg) * DD, F);
+      if (has_left) load_block<T, D>(Gp + (lv.offG[t] + kg - 1) * DD, G);
+    };
+    T Dl[D][D], F[D][D], G[D][D];
+    load_factors(INV_LP - 1, Dl, F, G);
+
+    // ---- relative levels 2 and 1 -------------------------------------------------------------
+#pragma unroll
+    for (int t = INV_LP - 1; t >= 1; --t) {
+      T Dn[D][D], Fn[D][D], Gn[D][D];
+      load_factors(t - 1, Dn, Fn, Gn);
+      const int st = 1 << (t - 1);
+      bool even, odd, has_odd, has_left; int m; int64_t kg;
+      geom(t, even, odd, has_odd, has_left, m, kg);
+      T SdR[D][D], SoR[D][D], SdL[D][D];
+      shfl_block<T, D>(SdR, Sdv, lane + st);
+      shfl_block<T, D>(SoR, Sov, lane + st);
+      shfl_block<T, D>(SdL, Sdv, lane - st);
+      if (m == 0) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) SdL[a][b] = SdLeft[a][b];
+      }
+      T See[D][D], oR[D][D], oL[D][D];
+      inverse_even_row<T, D>(Dl, F, G, SdR, SoR, SdL, has_odd, has_left, See, oR, oL);
+      T V[D][D];
+      shfl_block<T, D>(V, oR, lane - st);
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          if (even) { Sdv[a][b] = See[a][b]; Sov[a][b] = oL[a][b]; }
+          if (odd) Sov[a][b] = V[a][b];
+          Dl[a][b] = Dn[a][b]; F[a][b] = Fn[a][b]; G[a][b] = Gn[a][b];
+        }
+    }
+
+    // ---- relative level 0: lane k computes row 2k, holds row 2k+1 ------------------------------
+    {
+      bool even, odd, has_odd, has_left; int m; int64_t kg;
+      geom(0, even, odd, has_odd, has_left, m, kg);
+      T SdL[D][D];
+      shfl_block<T, D>(SdL, Sdv, lane - 1);
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) SdL[a][b] = SdLeft[a][b];
+      }
+      T See[D][D], oR[D][D], oL[D][D];
+      inverse_even_row<T, D>(Dl, F, G, Sdv, Sov, SdL, has_odd, has_left, See, oR, oL);
+      store_pairs_coalesced<T, D>(stage, Sd_out + row0 * DD, See, even, Sdv, has_odd, n0, 0);
+      // couplings So[row0 - 1 .. row0 + n0 - 2]: pair index 2k <-> Sigma[2k, 2k-1], 2k+1 <-> Sigma[2k+1, 2k]
+      store_pairs_coalesced<T, D>(stage, So_out + (row0 - 1) * DD, oL, even, oR, has_odd, n0, row0 == 0 ? 1 : 0);
+    }
+  }
+}
+
+}  // namespace cgps

@@ -261,12 +261,11 @@ __device__ __forceinline__ void mm_acc(T (&C)[D][D], const T (&A)[D][D], const T
 //   Sig[2k,2k]   = D_k^-T D_k^-1 + A_k^T M[k,k] + B_k-1^T M[k-1,k]
 //   Sig[2k+1,2k] = -M[k,k] ;  Sig[2k,2k-1] = -M[k-1,k]^T ;  Sig[2k+1,2k+1] = S~[k,k]
 template <typename T, int D>
-__global__ __launch_bounds__(LEVEL_THREADS) void inverse_level_kernel(
+__device__ __forceinline__ void inverse_level_row(
     const T* __restrict__ Dk, const T* __restrict__ Fk, const T* __restrict__ Gk,
-    const T* __restrict__ Sd_c, const T* __restrict__ So_c, int64_t n,
-    T* __restrict__ Sd, T* __restrict__ So) {
+    const T* __restrict__ Sd_c, const T* __restrict__ So_c, int64_t n, T* __restrict__ Sd, T* __restrict__ So,
+    int64_t k) {
   constexpr int DD = D * D;
-  const int64_t k = (int64_t)blockIdx.x * LEVEL_THREADS + threadIdx.x;
   const int64_t e = 2 * k;
   if (e >= n) return;
   const int64_t nf = n / 2;
@@ -330,6 +329,14 @@ __global__ __launch_bounds__(LEVEL_THREADS) void inverse_level_kernel(
     store_block<T, D>(So + (e - 1) * DD, negT);         // Sig[2k,2k-1]
   }
   store_block<T, D>(Sd + e * DD, See);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(LEVEL_THREADS) void inverse_level_kernel(
+    const T* __restrict__ Dk, const T* __restrict__ Fk, const T* __restrict__ Gk,
+    const T* __restrict__ Sd_c, const T* __restrict__ So_c, int64_t n,
+    T* __restrict__ Sd, T* __restrict__ So) {
+  inverse_level_row<T, D>(Dk, Fk, Gk, Sd_c, So_c, n, Sd, So, (int64_t)blockIdx.x * LEVEL_THREADS + threadIdx.x);
 }
 
 }  // namespace cgps
