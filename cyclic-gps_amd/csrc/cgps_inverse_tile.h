@@ -24,6 +24,12 @@ namespace cgps {
 constexpr int INV_LP = 3;
 constexpr int INV_TS = 128;
 constexpr int INV_NT = 64;
+// fp64 d = 4 needs ~335 registers: one wave per SIMD.  Forcing two (256 registers) spills 83 of
+// them to scratch and the big pass goes from 138 to 255 us; at one wave the chain of a tile
+// (input load -> three dependent levels -> stores) is what bounds the pass.
+#ifndef INV_MIN_WAVES
+#define INV_MIN_WAVES 1
+#endif
 
 struct InverseLevels {
   int64_t offD[INV_LP], offF[INV_LP], offG[INV_LP];   // packed-array offsets of levels L, L+1, L+2
@@ -98,12 +104,25 @@ __device__ __forceinline__ void inverse_even_row(const T (&Dl)[D][D], const T (&
         See[i][j] = sacc;
       }
   };
+  // C (+)= S X with S symmetric, only its lower triangle read: the callers then never need (nor
+  // shuffle, nor keep in registers) the upper triangles of the Sigma diagonal blocks
+  auto sym_times = [&](T (&C)[D][D], const T (&S)[D][D], const T (&X)[D][D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        T sacc = T(0);
+#pragma unroll
+        for (int m = 0; m < D; ++m) sacc = fmaT(m <= i ? S[i][m] : S[m][i], X[m][j], sacc);
+        C[i][j] = sacc;
+      }
+  };
   set_zero<T, D>(Ak);
   set_zero<T, D>(Bk);
   if (has_odd) times_di(Ak, F);                          // A_k = F_k D_k^-1
   if (has_left) times_di(Bk, G);                         // B_k-1 = G_k-1 D_k^-1
   if (has_odd) {
-    mm<T, D>(M, SdR, Ak);
+    sym_times(M, SdR, Ak);
     if (has_left) mm_acc<T, D>(M, SoR, Bk);
     acc_lower_tn(Ak, M);
 #pragma unroll
@@ -112,7 +131,7 @@ __device__ __forceinline__ void inverse_even_row(const T (&Dl)[D][D], const T (&
       for (int j = 0; j < D; ++j) oR[i][j] = -M[i][j];
   }
   if (has_left) {
-    mm<T, D>(M, SdL, Bk);
+    sym_times(M, SdL, Bk);
     if (has_odd) mm_tn_acc<T, D>(M, SoR, Ak);
     acc_lower_tn(Bk, M);
 #pragma unroll
@@ -159,10 +178,23 @@ __device__ __forceinline__ void store_pairs_coalesced(T* stage, T* __restrict__ 
       }
       __builtin_amdgcn_wave_barrier();
       V* dv = reinterpret_cast<V*>(dst) + (size_t)b0 * G;
+      if (lo == 0 && hi == 64) {
+        // full half: all LDS reads in flight before the first store (the rolled loop below pays
+        // an LDS round trip per 1 KB stored)
+        V tmp[G];
+#pragma unroll
+        for (int it = 0; it < G; ++it) {
+          const int v = it * 64 + lane, kk = v / G, g = v % G;
+          tmp[it] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+        }
+#pragma unroll
+        for (int it = 0; it < G; ++it) dv[it * 64 + lane] = tmp[it];
+      } else {
 #pragma unroll 1
-      for (int v = lo * G + lane; v < hi * G; v += 64) {
-        const int kk = v / G, g = v % G;
-        dv[v] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+        for (int v = lo * G + lane; v < hi * G; v += 64) {
+          const int kk = v / G, g = v % G;
+          dv[v] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+        }
       }
       __builtin_amdgcn_wave_barrier();
     } else {
@@ -187,7 +219,7 @@ __device__ __forceinline__ void store_pairs_coalesced(T* stage, T* __restrict__ 
 // One pass: Sigma of level L+3 (Sd_in[n >> 3], So_in[(n >> 3) - 1]) -> Sigma of level L
 // (Sd_out[n], So_out[n-1]); n = rows of level L, n >> 3 >= 1.  Dp/Fp/Gp: the packed factor.
 template <typename T, int D>
-__global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restrict__ Dp, const T* __restrict__ Fp,
+__global__ __launch_bounds__(INV_NT, INV_MIN_WAVES) void inverse_tile_kernel(const T* __restrict__ Dp, const T* __restrict__ Fp,
                                                               const T* __restrict__ Gp, InverseLevels lv,
                                                               const T* __restrict__ Sd_in, const T* __restrict__ So_in,
                                                               int64_t n, T* __restrict__ Sd_out,
@@ -204,10 +236,9 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
     const int n0 = (int)((n - row0) < INV_TS ? (n - row0) : INV_TS);
     const int64_t g3 = row0 >> INV_LP;
     const int n3 = n0 >> INV_LP;
-    T Sdv[D][D], Sov[D][D], SdLeft[D][D];
+    T Sdv[D][D], Sov[D][D];        // of Sdv only the lower triangle is kept up to date
     set_zero<T, D>(Sdv);
     set_zero<T, D>(Sov);
-    set_zero<T, D>(SdLeft);
     {
       const int m = ((lane + 1) >> 2) - 1;
       if (((lane + 1) & 3) == 0 && m < n3) {
@@ -215,11 +246,12 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
         if (g3 + m >= 1) load_block<T, D>(So_in + (g3 + m - 1) * DD, Sov);
       }
     }
-    if (row0 > 0) load_block<T, D>(Sd_in + (g3 - 1) * DD, SdLeft);
+    // the tile's first even row of every level: its left neighbour is the previous tile's last
+    // row (fetched when needed rather than kept: registers)
+    auto left_of_tile = [&](T (&SdL)[D][D]) {
+      if (row0 > 0) load_block<T, D>(Sd_in + (g3 - 1) * DD, SdL);
+    };
 
-    // The factor blocks of a level do not depend on Sigma: a level's D, F, G are requested one
-    // level ahead, so their HBM latency passes under the previous level's arithmetic (with one wave
-    // per SIMD nothing else hides it: 146 -> see DESIGN.md for the pass at N = 2^20).
     auto geom = [&](int t, bool& even, bool& odd, bool& has_odd, bool& has_left, int& m, int64_t& kg) {
       if (t == 0) {
         even = 2 * lane < n0; odd = false; has_odd = 2 * lane + 1 < n0; m = 2 * lane;
@@ -245,14 +277,12 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
       if (has_odd) load_block<T, D>(Fp + (lv.offF[t] + kg) * DD, F);
       if (has_left) load_block<T, D>(Gp + (lv.offG[t] + kg - 1) * DD, G);
     };
-    T Dl[D][D], F[D][D], G[D][D];
-    load_factors(INV_LP - 1, Dl, F, G);
 
     // ---- relative levels 2 and 1 -------------------------------------------------------------
 #pragma unroll
     for (int t = INV_LP - 1; t >= 1; --t) {
-      T Dn[D][D], Fn[D][D], Gn[D][D];
-      load_factors(t - 1, Dn, Fn, Gn);
+      T Dl[D][D], F[D][D], G[D][D];
+      load_factors(t, Dl, F, G);
       const int st = 1 << (t - 1);
       bool even, odd, has_odd, has_left; int m; int64_t kg;
       geom(t, even, odd, has_odd, has_left, m, kg);
@@ -260,12 +290,7 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
       shfl_block<T, D>(SdR, Sdv, lane + st);
       shfl_block<T, D>(SoR, Sov, lane + st);
       shfl_block<T, D>(SdL, Sdv, lane - st);
-      if (m == 0) {
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int b = 0; b < D; ++b) SdL[a][b] = SdLeft[a][b];
-      }
+      if (even && m == 0) left_of_tile(SdL);
       T See[D][D], oR[D][D], oL[D][D];
       inverse_even_row<T, D>(Dl, F, G, SdR, SoR, SdL, has_odd, has_left, See, oR, oL);
       T V[D][D];
@@ -276,7 +301,6 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
         for (int b = 0; b < D; ++b) {
           if (even) { Sdv[a][b] = See[a][b]; Sov[a][b] = oL[a][b]; }
           if (odd) Sov[a][b] = V[a][b];
-          Dl[a][b] = Dn[a][b]; F[a][b] = Fn[a][b]; G[a][b] = Gn[a][b];
         }
     }
 
@@ -284,16 +308,14 @@ __global__ __launch_bounds__(INV_NT) void inverse_tile_kernel(const T* __restric
     {
       bool even, odd, has_odd, has_left; int m; int64_t kg;
       geom(0, even, odd, has_odd, has_left, m, kg);
+      T Dl[D][D], F[D][D], G[D][D];
+      load_factors(0, Dl, F, G);
       T SdL[D][D];
       shfl_block<T, D>(SdL, Sdv, lane - 1);
-      if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int b = 0; b < D; ++b) SdL[a][b] = SdLeft[a][b];
-      }
+      if (lane == 0) left_of_tile(SdL);
       T See[D][D], oR[D][D], oL[D][D];
       inverse_even_row<T, D>(Dl, F, G, Sdv, Sov, SdL, has_odd, has_left, See, oR, oL);
+      mirror_lower<T, D>(Sdv);
       store_pairs_coalesced<T, D>(stage, Sd_out + row0 * DD, See, even, Sdv, has_odd, n0, 0);
       // couplings So[row0 - 1 .. row0 + n0 - 2]: pair index 2k <-> Sigma[2k, 2k-1], 2k+1 <-> Sigma[2k+1, 2k]
       store_pairs_coalesced<T, D>(stage, So_out + (row0 - 1) * DD, oL, even, oR, has_odd, n0, row0 == 0 ? 1 : 0);
