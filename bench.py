@@ -155,6 +155,17 @@ def extra_measurements(dev):
                            factor_solves_per_s=1.0 / (t_dec + t_sol),
                            solve_max_abs_err=float((xs.double() - x_true.double()).abs().max()))
                 del holder, xs
+            if name.startswith("opB"):
+                # a training step through the path (models.py:374-381): forward + analytic adjoint
+                # (backward = decompose + solve + inverse_blocks on the same kernels)
+                Rg, Og, bg = (t_.clone().requires_grad_(True) for t_ in (Rs, Os, b))
+
+                def step():
+                    mm, ll = cr.mahal_and_det(Rg, Og, bg)
+                    (mm + ll).backward()
+                    Rg.grad = Og.grad = bg.grad = None
+                res["mahal_and_det_fwd_bwd_us"] = _time_cuda(step, reps) * 1e6
+                del Rg, Og, bg
             out[name] = res
             del Rs, Os, b, x_true
             torch.cuda.empty_cache()

@@ -784,4 +784,20 @@ int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtyp
   });
 }
 
+int cgps_mahal_logdet_adjoint(void* Sd, void* So, const void* w, int64_t N, int d, int dtype, const void* gm,
+                              const void* gl, void* stream) {
+  if (bad_common(N, d) || !Sd || (N > 1 && !So) || !w || !gm || !gl)
+    return fail(CGPS_ERR_ARG, "cgps_mahal_logdet_adjoint: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const int64_t total = (2 * N - 1) * D * D;
+    int64_t nb = (total + cgps::ADJ_THREADS - 1) / cgps::ADJ_THREADS;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL((cgps::mahal_logdet_adjoint_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::ADJ_THREADS), 0,
+                       (hipStream_t)stream, (T*)Sd, (T*)So, (const T*)w, N, (const T*)gm, (const T*)gl);
+    return check_launch("mahal_logdet_adjoint");
+  });
+}
+
 }  // extern "C"

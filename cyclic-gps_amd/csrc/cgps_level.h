@@ -339,4 +339,27 @@ __global__ __launch_bounds__(LEVEL_THREADS) void inverse_level_kernel(
   inverse_level_row<T, D>(Dk, Fk, Gk, Sd_c, So_c, n, Sd, So, (int64_t)blockIdx.x * LEVEL_THREADS + threadIdx.x);
 }
 
+// Adjoint of mahal_and_det in the blocks, given Sigma's blocks (inverse_blocks) and w = J^-1 x:
+//   d/dR_i = gl Sigma[i,i] - gm w_i w_i^T,   d/dO_i = 2 (gl Sigma[i+1,i] - gm w_i+1 w_i^T)
+// in place over Sd / So, one pass (as batched torch ops: ten element-wise kernels over N d^2 arrays).
+constexpr int ADJ_THREADS = 256;
+template <typename T, int D>
+__global__ __launch_bounds__(ADJ_THREADS) void mahal_logdet_adjoint_kernel(T* __restrict__ Sd, T* __restrict__ So,
+                                                                           const T* __restrict__ w, int64_t N,
+                                                                           const T* __restrict__ gm_p,
+                                                                           const T* __restrict__ gl_p) {
+  constexpr int DD = D * D;
+  const T gm = *gm_p, gl = *gl_p;
+  const int64_t nd = N * DD, total = nd + (N - 1) * DD;
+  for (int64_t idx = (int64_t)blockIdx.x * ADJ_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * ADJ_THREADS) {
+    const bool diag = idx < nd;
+    const int64_t j = diag ? idx : idx - nd;
+    const int64_t i = j / DD;
+    const int r = (int)(j - i * DD), a = r / D, b = r - a * D;
+    if (diag) Sd[j] = gl * Sd[j] - gm * w[i * D + a] * w[i * D + b];
+    else So[j] = T(2) * (gl * So[j] - gm * w[(i + 1) * D + a] * w[i * D + b]);
+  }
+}
+
 }  // namespace cgps

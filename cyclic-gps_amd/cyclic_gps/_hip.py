@@ -34,6 +34,7 @@ _SIGNATURES = {
     "cgps_solve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "cgps_logdet_factor": (_int, [_vp, _i64, _int, _int, _vp, _sz, _vp, _vp]),
     "cgps_inverse_blocks": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cgps_mahal_logdet_adjoint": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "cgps_peg_precision": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "cgps_record_elems": (_int, [_int, _int, ctypes.POINTER(_i64)]),
     "cgps_shard_reduce": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),

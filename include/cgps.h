@@ -114,6 +114,16 @@ int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype,
 int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
                         void* Sd, void* So, void* ws, size_t ws_bytes, void* stream);
 
+/* Adjoint of mahal_and_det in the blocks (what autograd computes through cyclic_reduction.py:380-438
+ * for LEGFamily.training_step, models.py:374-381).  Given Sd/So = inverse_blocks(decomp),
+ * w[N][d] = solve(decomp, x) and the two upstream gradients gm, gl (DEVICE scalars of the blocks'
+ * dtype: d loss / d mahal, d loss / d logdet), overwrites in place
+ *   Sd[i] <- gl Sd[i] - gm w_i w_i^T            (= d loss / d Rs[i])
+ *   So[i] <- 2 (gl So[i] - gm w_i+1 w_i^T)      (= d loss / d Os[i])
+ * d loss / d x = 2 gm w is the caller's.  No workspace. */
+int cgps_mahal_logdet_adjoint(void* Sd, void* So, const void* w, int64_t N, int d, int dtype,
+                              const void* gm, const void* gl, void* stream);
+
 /* ---- operand assembly for LEG models (the caller's step right before the path) ---------------
  * Blocks of the PEG prior precision from the time stamps and the generator G
  * (models.py:181-239: E_i = exp(-1/2 (t_{i+1}-t_i) G), two d x d solves per gap):

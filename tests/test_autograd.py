@@ -32,6 +32,28 @@ def test_mahal_and_det_gradients_match_reference_autograd():
         np.testing.assert_allclose(gv, g["g_%s_v" % name], **T)
 
 
+@pytest.mark.parametrize("d,dtype,n", [(1, torch.float64, 1), (2, torch.float64, 2), (3, torch.float64, 37),
+                                       (4, torch.float64, 70001), (4, torch.float32, 5000), (8, torch.float32, 1000)])
+def test_mahal_and_det_adjoint_kernel(d, dtype, n):
+    """cgps_mahal_logdet_adjoint (both upstream gradients at once, CPU and GPU callers) against
+    dR = gl Sigma_diag - gm w w^T, dO = 2 (gl Sigma_off - gm w[1:] w[:-1]^T), dx = 2 gm w."""
+    Rs, Os, b, _, _ = _util.conditioned_system(n, d, dtype=dtype, seed=5 + n)
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-5)
+    for dev in ("cuda", "cpu"):
+        R, O, v = (t.to(dev).clone().requires_grad_(True) for t in (Rs, Os, b))
+        m, ld = cr.mahal_and_det(R, O, v)
+        (0.7 * m - 1.3 * ld).backward()
+        dec = cr.decompose(Rs.cuda(), Os.cuda())
+        w = cr.solve(dec, b.cuda())
+        Sd, So = cr.inverse_blocks(dec)
+        eR = -1.3 * Sd - 0.7 * w.unsqueeze(-1) * w.unsqueeze(-2)
+        eO = 2 * (-1.3 * So - 0.7 * w[1:].unsqueeze(-1) * w[:-1].unsqueeze(-2))
+        assert R.grad.device.type == dev
+        np.testing.assert_allclose(R.grad.cpu().numpy(), eR.cpu().numpy(), **tol)
+        np.testing.assert_allclose(O.grad.cpu().numpy(), eO.cpu().numpy(), **tol)
+        np.testing.assert_allclose(v.grad.cpu().numpy(), (1.4 * w).cpu().numpy(), **tol)
+
+
 def test_det_and_solve_gradients_match_reference_autograd():
     g = np.load(os.path.join(_util.GOLDEN, "grad_d3_n37.npz"))
     R, O, v = _leaves(g)

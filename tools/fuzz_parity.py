@@ -61,9 +61,18 @@ def main():
         x = cr.solve(dec, b)
         e3 = float((x.double() - x_true.double()).abs().max())
         e4 = abs(float(cr.det(dec)) - logdet) / max(1.0, abs(logdet))
-        err = max(e1, e2 / 10, e3 / 10, e4)
+        # selected inverse: the block-diagonal of J Sigma = I only involves the blocks inverse_blocks
+        # returns: R_i S[i,i] + O_i-1 S[i,i-1]^T + O_i^T S[i+1,i] = I
+        Sd, So = cr.inverse_blocks(dec)
+        res = Rs @ Sd
+        if n > 1:
+            res[1:] += Os @ So.transpose(1, 2)
+            res[:-1] += Os.transpose(1, 2) @ So
+        res -= torch.eye(d, dtype=dtype, device="cuda")
+        e5 = float(res.abs().max()) * (1.0 if dtype == torch.float64 else 0.1)
+        err = max(e1, e2 / 10, e3 / 10, e4, e5 / 10)
         if not err <= tol:
-            print("FAIL", tag, "logdet %.3e mahal %.3e solve %.3e det %.3e" % (e1, e2, e3, e4), flush=True)
+            print("FAIL", tag, "logdet %.3e mahal %.3e solve %.3e det %.3e inverse %.3e" % (e1, e2, e3, e4, e5), flush=True)
             sys.exit(1)
         if dtype == torch.float64:
             worst64 = max(worst64, err)
