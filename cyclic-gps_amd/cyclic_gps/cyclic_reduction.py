@@ -193,6 +193,16 @@ def _outer(a, b):
     return a.unsqueeze(-1) * b.unsqueeze(-2)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 class _MahalLogdetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Rs, Os, x):
@@ -203,12 +213,25 @@ class _MahalLogdetFn(torch.autograd.Function):
     def backward(ctx, gm, gl):
         Rs, Os, x = ctx.saved_tensors
         dec = _decompose_raw(Rs, Os)
-        w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
+        need_blocks = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         gR = gO = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if need_blocks and Rs.is_cuda and Os.is_cuda and x.is_cuda:
+            # the solve (bandwidth-bound sweeps) and the selected inverse (latency-bound chain, one
+            # wave per SIMD) only share the factor: run them side by side on two streams
+            main, side = torch.cuda.current_stream(Rs.device), _side_stream(Rs.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
+            gR, gO = inverse_blocks(dec)
+            main.wait_stream(side)
+            w.record_stream(main)
+        else:
+            w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
+            if need_blocks:
+                gR, gO = inverse_blocks(dec)
+        if need_blocks:
             # gR = gl Sigma_diag - gm w w^T, gO = 2 (gl Sigma_off - gm w[1:] w[:-1]^T), written over
             # the blocks inverse_blocks just produced (one pass instead of ten element-wise kernels)
-            gR, gO = inverse_blocks(dec)
             if gR.is_cuda:
                 N, d = gR.shape[0], gR.shape[1]
                 wd = w.to(gR.dtype).contiguous()
