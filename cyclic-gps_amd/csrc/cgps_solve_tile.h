@@ -30,7 +30,7 @@ constexpr int SOLVE_MAXLEV = SOLVE_LP + 1;
 constexpr int SOLVE_LP_WIDE = 3;                  // levels per pass while the system is large ...
 constexpr int64_t SOLVE_WIDE_ROWS = 1 << 20;      // ... i.e. has at least this many rows (2^18 .. 2^20 measured alike)
 template <typename T, int D> constexpr size_t solve_lds_bytes() {
-  return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double);
+  return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double) + D * sizeof(T);
 }
 
 // offsets (in blocks) of the levels one pass covers, and their sizes
@@ -106,9 +106,14 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
   __syncthreads();
   double mah = 0.0, zero = 0.0;
   int nj = n0;
-  T owed[D];                                             // lane 0: sum_j G_j x_j of the tile's first rows
+  // thread 0 only: sum_j G_j x_j of the tile's first rows.  In LDS rather than in registers: the
+  // 2 D registers it would pin in every lane are what separates 69 from 64 VGPRs, i.e. three from
+  // four resident workgroups per CU -- and 1024 tiles (N = 2^20) from fitting the chip in one round.
+  T* owed = reinterpret_cast<T*>(red + 2 * (SOLVE_NT / 64));
+  if (tid == 0) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) owed[i] = T(0);
+    for (int i = 0; i < D; ++i) owed[i] = T(0);
+  }
   for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
     const int ne = (nj + 1) >> 1, no = nj >> 1;
     const int64_t g0 = row0 >> (j + 1);
@@ -128,9 +133,12 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
         T G[D][D];
         load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, G);
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+        for (int i = 0; i < D; ++i) {
+          T acc = owed[i];
 #pragma unroll
-          for (int m2 = 0; m2 < D; ++m2) owed[i] = fmaT(G[i][m2], x[m2], owed[i]);
+          for (int m2 = 0; m2 < D; ++m2) acc = fmaT(G[i][m2], x[m2], acc);
+          owed[i] = acc;
+        }
       }
     }
     __syncthreads();
@@ -159,7 +167,11 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
       store_vec<T, D>(y_out + ((size_t)blockIdx.x * spt_out + r) * D, v);
     }
   }
-  if (owed_out != nullptr && tid == 0) store_vec<T, D>(owed_out + (size_t)blockIdx.x * D, owed);
+  if (owed_out != nullptr && tid == 0) {
+    T ow[D];
+    lds_load_vec<T, D>(owed, ow);
+    store_vec<T, D>(owed_out + (size_t)blockIdx.x * D, ow);
+  }
   block_sum2<SOLVE_NT>(mah, zero, red);
   if (tid == 0 && partial != nullptr) {
     partial[2 * (size_t)blockIdx.x] = mah;
