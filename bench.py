@@ -184,6 +184,18 @@ def extra_measurements(dev):
             "solve_us": _time_cuda(lambda: cr.solve(holder["dec"], b), 50) * 1e6,
             "logdet_rel_err": abs(float(cr.mahal_and_det(Rs, Os, b)[1]) - logdet_true) / abs(logdet_true),
         }
+        # the same call captured in a HIP graph and replayed (what a caller's optimiser loop would do)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            cr.mahal_and_det(Rs, Os, b)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gm, gl = cr.mahal_and_det(Rs, Os, b)
+        out["c1_N1024_d2_f64"]["mahal_and_det_graph_replay_us"] = _time_cuda(graph.replay, 50) * 1e6
+        out["c1_N1024_d2_f64"]["graph_logdet_rel_err"] = abs(float(gl) - logdet_true) / abs(logdet_true)
+        del graph
     except Exception as e:
         out["c1_N1024_d2_f64"] = {"error": repr(e)[:200]}
     try:
