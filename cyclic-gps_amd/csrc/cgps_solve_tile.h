@@ -33,6 +33,10 @@ template <typename T, int D> constexpr size_t solve_lds_bytes() {
   return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double) + D * sizeof(T);
 }
 
+// Blocks of <= 128 bytes: hold the forward sweep to 64 registers (it needs 65 otherwise), i.e. four
+// resident workgroups per CU; larger blocks need more registers than that anyway.
+template <typename T, int D> constexpr int solve_min_waves() { return (size_t)D * D * sizeof(T) <= 128 ? 8 : 1; }
+
 // offsets (in blocks) of the levels one pass covers, and their sizes
 struct PassLevels {
   int64_t offD[SOLVE_MAXLEV], offF[SOLVE_MAXLEV], offG[SOLVE_MAXLEV], m[SOLVE_MAXLEV];
@@ -52,6 +56,13 @@ __device__ __forceinline__ void warm_l2(const T* p, int64_t elems) {
   asm volatile("" ::"v"(acc));
 }
 
+template <typename T, int D>
+__device__ __forceinline__ void set_zero_block(T (&A)[D][D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) A[i][j] = T(0);
+}
 template <typename T, int D>
 __device__ __forceinline__ void lds_load_vec(const T* p, T (&v)[D]) {
 #pragma unroll
@@ -73,7 +84,7 @@ __device__ __forceinline__ void lds_store_vec(T* p, const T (&v)[D]) {
 // owed_out[tile] : what this tile's first rows owe the previous tile's LAST surviving row
 //         (spt_in = survivors per tile of the pass that wrote owed_in).
 template <typename T, int D>
-__global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
+__global__ __launch_bounds__(SOLVE_NT, (solve_min_waves<T, D>())) void halfsolve_tile_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
     const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int64_t n,
     T* __restrict__ xcrr, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
@@ -89,6 +100,11 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
     warm_l2(Fp + lv.offF[0] * DD, (lv.endF - lv.offF[0]) * DD);
     warm_l2(Gp + lv.offG[0] * DD, (lv.endG - lv.offG[0]) * DD);
   }
+  // The first level's D block of this lane does not depend on anything: request it now, so that
+  // its latency passes under the load of the tile's rows instead of behind the barrier that follows.
+  T L0[D][D];
+  if (tid < ((n0 + 1) >> 1)) load_block<T, D>(Dp + (lv.offD[0] + (row0 >> 1) + tid) * DD, L0);
+  else set_zero_block(L0);
   // load (and complete) the tile's rows
   for (int r = tid; r < n0; r += SOLVE_NT) {
     T v[D];
@@ -114,34 +130,48 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
 #pragma unroll
     for (int i = 0; i < D; ++i) owed[i] = T(0);
   }
-  for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
-    const int ne = (nj + 1) >> 1, no = nj >> 1;
+  // elimination k of local level j: x_k = D_k^-1 y_2k (y handed in registers), x into the row's
+  // slot and into xcrr; the tile's first elimination also owes G x to the previous tile's last row
+  auto eliminate_with = [&](int j, int k, const T (&L)[D][D], T (&x)[D]) {
     const int64_t g0 = row0 >> (j + 1);
-    for (int k = tid; k < ne; k += SOLVE_NT) {           // x_k = D_k^-1 y_2k
-      T L[D][D], x[D];
-      Chol<T, D> c;
-      load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
-      chol_from_dense<T, D>(L, c);
-      T* slot = ys + (size_t)(((2 * k + 1) << j) - 1) * D;
-      lds_load_vec<T, D>(slot, x);
-      fwd_subst<T, D>(c, x);
-      lds_store_vec<T, D>(slot, x);
-      store_vec<T, D>(xcrr + (lv.offD[j] + g0 + k) * D, x);
+    Chol<T, D> c;
+    chol_from_dense<T, D>(L, c);
+    fwd_subst<T, D>(c, x);
+    lds_store_vec<T, D>(ys + (size_t)(((2 * k + 1) << j) - 1) * D, x);
+    store_vec<T, D>(xcrr + (lv.offD[j] + g0 + k) * D, x);
 #pragma unroll
-      for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
-      if (k == 0 && g0 >= 1) {                           // the previous tile's last row is this row's left neighbour
-        T G[D][D];
-        load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, G);
+    for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+    if (k == 0 && g0 >= 1) {                             // the previous tile's last row is this row's left neighbour
+      T G[D][D];
+      load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, G);
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-          T acc = owed[i];
+      for (int i = 0; i < D; ++i) {
+        T acc = owed[i];
 #pragma unroll
-          for (int m2 = 0; m2 < D; ++m2) acc = fmaT(G[i][m2], x[m2], acc);
-          owed[i] = acc;
-        }
+        for (int m2 = 0; m2 < D; ++m2) acc = fmaT(G[i][m2], x[m2], acc);
+        owed[i] = acc;
       }
     }
-    __syncthreads();
+  };
+  auto eliminate = [&](int j, int k, T (&x)[D]) {
+    T L[D][D];
+    load_block<T, D>(Dp + (lv.offD[j] + (row0 >> (j + 1)) + k) * DD, L);
+    eliminate_with(j, k, L, x);
+  };
+  // One barrier per level: the lane that completes an odd row 2k+1 of level j (= row k of level
+  // j+1) goes straight on to eliminate it when k is even, instead of parking it in LDS for a
+  // separate phase behind another barrier.
+  for (int k = tid; k < ((nj + 1) >> 1); k += SOLVE_NT) {
+    T x[D];
+    lds_load_vec<T, D>(ys + (size_t)(2 * k) * D, x);
+    if (k == tid) eliminate_with(0, k, L0, x);           // requested before the tile's rows were loaded
+    else eliminate(0, k, x);
+  }
+  __syncthreads();
+  for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
+    const int no = nj >> 1;
+    const int64_t g0 = row0 >> (j + 1);
+    const bool more = j + 1 < lv.nlev;
     for (int k = tid; k < no; k += SOLVE_NT) {           // y'_k = y_2k+1 - F_k x_k - G_k x_k+1
       T M[D][D], x[D], yo[D];
       T* slot = ys + (size_t)(((2 * k + 2) << j) - 1) * D;
@@ -154,7 +184,11 @@ __global__ __launch_bounds__(SOLVE_NT) void halfsolve_tile_kernel(
         lds_load_vec<T, D>(ys + (size_t)(((2 * k + 3) << j) - 1) * D, x);
         gemv_sub<T, D>(yo, M, x);
       }
-      lds_store_vec<T, D>(slot, yo);
+      if (more && (k & 1) == 0) {
+        eliminate(j + 1, k >> 1, yo);
+      } else {
+        lds_store_vec<T, D>(slot, yo);
+      }
     }
     __syncthreads();
     nj = no;
