@@ -188,12 +188,12 @@ __device__ __forceinline__ void store_pairs_coalesced(T* stage, T* __restrict__ 
           tmp[it] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
         }
 #pragma unroll
-        for (int it = 0; it < G; ++it) dv[it * 64 + lane] = tmp[it];
+        for (int it = 0; it < G; ++it) store_streaming16(&dv[it * 64 + lane], &tmp[it]);
       } else {
 #pragma unroll 1
         for (int v = lo * G + lane; v < hi * G; v += 64) {
           const int kk = v / G, g = v % G;
-          dv[v] = sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)];
+          store_streaming16(&dv[v], &sv[kk * G + (SWZ ? (g ^ (kk & (G - 1))) : g)]);
         }
       }
       __builtin_amdgcn_wave_barrier();
