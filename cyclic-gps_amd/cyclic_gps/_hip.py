@@ -4,6 +4,7 @@ The library is the product: if it is missing this module raises, it never falls
 back to a CPU or torch implementation.
 """
 import ctypes
+import functools
 import os
 
 import torch
@@ -93,13 +94,25 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def level_layout(N):
-    """(ms, offD, offF, offG) python lists; offsets have one extra entry (the total)."""
+@functools.lru_cache(maxsize=512)
+def _level_layout_cached(N):
     n = _int(0)
     arrs = [(ctypes.c_int64 * (MAX_LEVELS + 1))() for _ in range(4)]
     check(lib().cgps_level_layout(N, ctypes.byref(n), *arrs))
     L = n.value
-    return (list(arrs[0][:L]), list(arrs[1][:L + 1]), list(arrs[2][:L + 1]), list(arrs[3][:L + 1]))
+    return (tuple(arrs[0][:L]), tuple(arrs[1][:L + 1]), tuple(arrs[2][:L + 1]), tuple(arrs[3][:L + 1]))
+
+
+def level_layout(N):
+    """(ms, offD, offF, offG) python lists; offsets have one extra entry (the total)."""
+    return tuple(list(t) for t in _level_layout_cached(int(N)))
+
+
+@functools.lru_cache(maxsize=2048)
+def _workspace_bytes(N, d, dtc, op):
+    b = _sz(0)
+    check(lib().cgps_workspace_bytes(N, d, dtc, op, ctypes.byref(b)))
+    return b.value
 
 
 _ws_cache = {}
@@ -107,11 +120,10 @@ _ws_cache = {}
 
 def workspace(N, d, dt, op, device):
     """A cached scratch tensor of the size the library asks for (torch owns the memory)."""
-    b = _sz(0)
-    check(lib().cgps_workspace_bytes(N, d, dtype_code(dt), op, ctypes.byref(b)))
+    nbytes = _workspace_bytes(int(N), int(d), dtype_code(dt), int(op))
     key = (device, torch.cuda.current_stream().cuda_stream)
     cur = _ws_cache.get(key)
-    if cur is None or cur.numel() < b.value:
-        cur = torch.empty(max(b.value, 256), dtype=torch.uint8, device=device)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = cur
-    return cur, b.value
+    return cur, nbytes

@@ -91,10 +91,11 @@ class CRDecomp(tuple):
 def _views(Dp, Fp, Gp, N):
     ms, offD, offF, offG = _hip.level_layout(N)
     L = len(ms)
-    Ds = [Dp[offD[i]:offD[i + 1]] for i in range(L)]
-    Fs = [Fp[offF[i]:offF[i + 1]] for i in range(L - 1)]
-    Gs = [Gp[offG[i]:offG[i + 1]] for i in range(L - 1)]
-    return torch.tensor(ms, dtype=torch.int64), Ds, Fs, Gs
+
+    def cut(P, off, count):                      # one split call instead of one slice per level
+        sizes = [off[i + 1] - off[i] for i in range(count)]
+        return list(P[:off[count]].split(sizes)) if count else []
+    return torch.tensor(ms, dtype=torch.int64), cut(Dp, offD, L), cut(Fp, offF, L - 1), cut(Gp, offG, L - 1)
 
 
 def _packed(decomp):
