@@ -250,6 +250,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # CGPS_BENCH_REHEARSAL_GLOO=1: several ranks on ONE GPU over gloo -- exercises the multi-process
+    # flow (shard kernels with a left neighbour, the collective, the finish kernel) on a 1-GPU box;
+    # its timing means nothing
+    rehearsal = os.environ.get("CGPS_BENCH_REHEARSAL_GLOO") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
@@ -266,7 +272,10 @@ def main():
         import torch.distributed as dist
         from cyclic_gps import sharded
         if use_dist:
-            dist.init_process_group("nccl", device_id=dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
     n_total = rows * world
 
     # ---- synthetic system, resident in HBM ------------------------------------------------
