@@ -1,0 +1,128 @@
+// cgps_decompose.hip -- factor-emitting decompose
+// One translation unit of libcgps (include/cgps.h); host code only decides sizes/offsets and
+// enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
+#include "cgps_host.h"
+#include "cgps_tile.h"
+#include "cgps_decomp_tile.h"
+#include "cgps_decomp_lds.h"
+
+using namespace cgps_host;
+
+namespace {
+// ---- fused (tiled) factorisation: cgps_decomp_tile.h (bulk passes) + cgps_decomp_lds.h (tail) ----
+constexpr int64_t DEC_SMALL_ROWS = 32768;   // at or below this many rows a pass is latency-bound
+template <typename T, int D>
+int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
+                       hipStream_t st) {
+  using RL = cgps::RecordLayout<T, D>;
+  LevelWs w = level_ws(N, D, sizeof(T), true, false);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  // persistent waves: as many workgroups (one wave each) as the chip holds at once
+  const size_t lds = (size_t)64 * D * D * sizeof(T);      // staging of the coalesced factor stores
+  struct Caps { int64_t c[2]; };
+  static PerDevice<Caps> caps;                          // per device, filled once (thread-safe)
+  const size_t lds_small = cgps::decomp_lds_tile_bytes<T, D>();
+  const Caps& grid_caps = caps.get([&](int dev) {
+    int nb0 = 4, nb1 = 4;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, cgps::decomp_tile_kernel<T, D, false>, cgps::DEC_NT, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, cgps::decomp_tile_kernel<T, D, true>, cgps::DEC_NT, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small);
+    const int cus = device_cus(dev);
+    return Caps{{(int64_t)cus * (nb0 > 0 ? nb0 : 1), (int64_t)cus * (nb1 > 0 ? nb1 : 1)}};
+  });
+  const int64_t* grid_cap = grid_caps.c;
+  (void)hipMemsetAsync(info, 0, sizeof(int), st);
+  T* recs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};   // records of a pass
+  const T* rin = nullptr;
+  int64_t n_rec = 0;
+  int lvl = 0, p = 0, spt_in = 1;
+  while (lvl < L.nlevels) {
+    const int64_t rows = L.ms[lvl];
+    const int remaining = L.nlevels - lvl;
+    if (rows <= DEC_SMALL_ROWS) {
+      // latency-bound tail (or a small system): 256-row tiles in LDS, 8 levels per launch, four
+      // waves per elimination (cgps_decomp_lds.h); one record per tile
+      const int64_t g = (rows + cgps::DECL_TS - 1) / cgps::DECL_TS;
+      const int nl = (g == 1) ? remaining : cgps::DECL_LP;                 // <= DECL_LP + 1
+      cgps::DecompLevelsL dl;
+      dl.nlev = nl;
+      for (int j = 0; j < cgps::DECL_MAXLEV; ++j) {
+        const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+        dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+      }
+      T* rout = recs[p & 1];
+      if (p == 0)
+        hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, false>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds_small, st,
+                           Rs, Os, rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
+      else
+        hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, true>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds_small, st,
+                           rin, (const T*)nullptr, rows, n_rec, spt_in, dl, lvl, Dp, Fp, Gp, rout, info);
+      rin = rout;
+      n_rec = g;
+      spt_in = 1;
+      lvl += nl;
+      ++p;
+      continue;
+    }
+    const int64_t g = (rows + cgps::DEC_TS - 1) / cgps::DEC_TS;
+    const bool top = g == 1;                                               // one tile takes it to the end
+    // many tiles: a few levels per pass keep the lanes busy; few tiles: all levels of a tile
+    const int nl = top ? remaining : (g >= cgps::DEC_FEW_TILES ? cgps::DEC_LP : cgps::DEC_TS_LOG2);   // <= DEC_MAXLEV
+    cgps::DecompLevels dl;
+    dl.nlev = nl;
+    for (int j = 0; j < cgps::DEC_MAXLEV; ++j) {
+      const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+      dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+    }
+    T* rout = top ? nullptr : recs[p & 1];
+    const int64_t cap = grid_cap[p == 0 ? 0 : 1];
+    const unsigned grid = (unsigned)(g < cap ? g : cap);
+    if (p == 0)
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false>), dim3(grid), dim3(cgps::DEC_NT), lds, st, Rs, Os,
+                         rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
+    else
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, true>), dim3(grid), dim3(cgps::DEC_NT), lds, st, rin,
+                         (const T*)nullptr, rows, n_rec, spt_in, dl, lvl, Dp, Fp, Gp, rout, info);
+    rin = rout;
+    // every tile leaves DEC_TS >> nl records, the last one what survives of it, at least one
+    {
+      const int64_t spt = cgps::DEC_TS >> nl;
+      const int64_t last = (rows - (g - 1) * cgps::DEC_TS) >> nl;
+      n_rec = (g - 1) * spt + (last > 0 ? last : 1);
+      spt_in = (int)(spt > 0 ? spt : 1);
+    }
+    lvl += nl;
+    ++p;
+  }
+  (void)RL::STRIDE;
+  return check_launch("decompose (tiled)");
+}
+}  // namespace
+
+extern "C" {
+
+int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, void* Dp, void* Fp, void* Gp, void* ws,
+                   size_t ws_bytes, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !Dp || !Fp || !Gp || !ws || !info)
+    return fail(CGPS_ERR_ARG, "cgps_decompose: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    // tiled form for every block size whose 256-row tile fits the LDS (no register spills up to
+    // 8x8 fp32 / 5x5 fp64); larger blocks go level by level
+    if constexpr (cgps::tile_supported<T, D>()) {
+      if (!levelwise_solve_requested())
+        return run_decompose_tile<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, ws_bytes,
+                                        info, (hipStream_t)stream);
+    }
+    return run_levelwise<T, D>((const T*)Rs, (const T*)Os, nullptr, N, (T*)Dp, (T*)Fp, (T*)Gp, nullptr, (char*)ws,
+                               ws_bytes, nullptr, info, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// cgps_inverse.hip -- inverse_blocks and the adjoint pass of mahal_and_det
+// One translation unit of libcgps (include/cgps.h); host code only decides sizes/offsets and
+// enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
+#include "cgps_host.h"
+#include "cgps_tile.h"
+#include "cgps_inverse_tile.h"
+
+using namespace cgps_host;
+
+namespace {
+constexpr int64_t INV_FUSED_MIN_ROWS = 1024;   // a fused inverse pass must produce at least this many rows
+template <typename T, int D>
+int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, char* ws, size_t ws_bytes,
+                hipStream_t st) {
+  const int64_t cap = N / 2 + 1;
+  const size_t one = align_up((size_t)2 * D * D * sizeof(T) * cap);
+  if (ws_bytes < 2 * one) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, 2 * one);
+  Layout L;
+  make_layout(N, L);
+  T* bufs[2] = {reinterpret_cast<T*>(ws), reinterpret_cast<T*>(ws + one)};
+  const T *Sdc = nullptr, *Soc = nullptr;
+  // The coarse levels one launch each (latency-bound, little data); once a level that is a
+  // multiple of INV_LP above level 0 is reached and the rows get many, INV_LP levels per launch
+  // (cgps_inverse_tile.h): those passes read 1/8 of what they write instead of ping-ponging every
+  // level's Sigma through HBM.
+  constexpr bool FUSED = (size_t)D * D * sizeof(T) <= 128;
+  const size_t lds = (size_t)64 * D * D * sizeof(T);
+  static PerDevice<int> grid_caps;                    // persistent waves: what this device holds at once
+  const int grid_cap = !FUSED ? 1 : grid_caps.get([&](int dev) {
+    int nb = 2;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, cgps::inverse_tile_kernel<T, D>, cgps::INV_NT, lds);
+    return device_cus(dev) * (nb > 0 ? nb : 1);
+  });
+  int p = 0;
+  for (int l = L.nlevels - 1; l >= 0;) {
+    const int have = l + 1;                               // Sdc / Soc hold Sigma of this level
+    if (FUSED && Sdc != nullptr && have % cgps::INV_LP == 0 && L.ms[have] >= 1 &&
+        L.ms[have - cgps::INV_LP] >= INV_FUSED_MIN_ROWS) {
+      const int lf = have - cgps::INV_LP;
+      const int64_t n = L.ms[lf], tiles = (n + cgps::INV_TS - 1) / cgps::INV_TS;
+      cgps::InverseLevels lv;
+      for (int t = 0; t < cgps::INV_LP; ++t) {
+        lv.offD[t] = L.offD[lf + t]; lv.offF[t] = L.offF[lf + t]; lv.offG[t] = L.offG[lf + t];
+      }
+      T* od = (lf == 0) ? Sd : bufs[p];
+      T* oo = (lf == 0) ? So : bufs[p] + cap * D * D;
+      const int64_t grid = tiles < grid_cap ? tiles : grid_cap;
+      hipLaunchKernelGGL((cgps::inverse_tile_kernel<T, D>), dim3((unsigned)grid), dim3(cgps::INV_NT), lds, st, Dp, Fp,
+                         Gp, lv, Sdc, Soc, n, od, oo);
+      Sdc = od; Soc = oo; p ^= 1;
+      l = lf - 1;
+      continue;
+    }
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* od = (l == 0) ? Sd : bufs[p];
+    T* oo = (l == 0) ? So : bufs[p] + cap * D * D;
+    hipLaunchKernelGGL((cgps::inverse_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D, Sdc, Soc, n, od, oo);
+    Sdc = od; Soc = oo; p ^= 1;
+    --l;
+  }
+  return check_launch("inverse_blocks");
+}
+}  // namespace
+
+extern "C" {
+
+int cgps_inverse_blocks(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, void* Sd, void* So,
+                        void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !Sd || (N > 1 && !So) || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_inverse_blocks: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_inverse<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (T*)Sd, (T*)So, (char*)ws, ws_bytes,
+                             (hipStream_t)stream);
+  });
+}
+
+int cgps_mahal_logdet_adjoint(void* Sd, void* So, const void* w, int64_t N, int d, int dtype, const void* gm,
+                              const void* gl, void* stream) {
+  if (bad_common(N, d) || !Sd || (N > 1 && !So) || !w || !gm || !gl)
+    return fail(CGPS_ERR_ARG, "cgps_mahal_logdet_adjoint: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const int64_t total = (2 * N - 1) * D * D;
+    int64_t nb = (total + cgps::ADJ_THREADS - 1) / cgps::ADJ_THREADS;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL((cgps::mahal_logdet_adjoint_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::ADJ_THREADS), 0,
+                       (hipStream_t)stream, (T*)Sd, (T*)So, (const T*)w, N, (const T*)gm, (const T*)gl);
+    return check_launch("mahal_logdet_adjoint");
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// cgps_leg.hip -- operand assembly for LEG models
+// One translation unit of libcgps (include/cgps.h); host code only decides sizes/offsets and
+// enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
+#include "cgps_host.h"
+#include "cgps_leg.h"
+
+using namespace cgps_host;
+
+extern "C" {
+
+int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtype, void* Rs, void* Os, int* info,
+                       void* stream) {
+  if (bad_common(N, d) || !ts || !G || !Rs || (N > 1 && !Os) || !info)
+    return fail(CGPS_ERR_ARG, "cgps_peg_precision: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(info, 0, sizeof(int), st);
+    const int64_t nb = (N + cgps::LEG_THREADS - 1) / cgps::LEG_THREADS;
+    hipLaunchKernelGGL((cgps::peg_precision_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEG_THREADS), 0, st,
+                       (const T*)ts, (const T*)G, N, (T*)Rs, (T*)Os, info);
+    return check_launch("peg_precision");
+  });
+}
+
+}  // extern "C"

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(LEVEL_THREADS) void level_kernel(
 }
 
 // out[0] = sum partial[.][0] ; out[1] = sum partial[.][1]   (fixed order: deterministic)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int64_t count,
+static __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int64_t count,
                                                            double* __restrict__ out) {
   __shared__ double red[2 * 4];
   double a = 0.0, b = 0.0;

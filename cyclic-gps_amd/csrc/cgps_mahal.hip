@@ -1,0 +1,81 @@
+// cgps_mahal.hip -- fused solve + log-det (mahal_and_det), shard reduce / finish
+// One translation unit of libcgps (include/cgps.h); host code only decides sizes/offsets and
+// enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
+#include "cgps_host.h"
+#include "cgps_tile.h"
+
+using namespace cgps_host;
+
+extern "C" {
+
+int cgps_mahal_logdet(const void* Rs, const void* Os, const void* x, int64_t N, int d, int dtype, void* ws,
+                      size_t ws_bytes, double* out2, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !x || !ws || !out2 || !info)
+    return fail(CGPS_ERR_ARG, "cgps_mahal_logdet: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if constexpr (!cgps::tile_supported<T, D>()) {
+      return run_levelwise<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, nullptr, nullptr, nullptr, nullptr,
+                                 (char*)ws, ws_bytes, out2, info, (hipStream_t)stream);
+    } else {
+      int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, N, (char*)ws, ws_bytes,
+                                                 out2, info, (hipStream_t)stream, g_prof_start, g_prof_stop);
+      g_prof_start = g_prof_stop = nullptr;
+      if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_mahal_logdet");
+      return check_launch("tile reduction");
+    }
+  });
+}
+
+int cgps_record_elems(int d, int dtype, int64_t* elems) {
+  if (!elems || d < 1) return fail(CGPS_ERR_ARG, "cgps_record_elems: bad argument");
+  if (d > 8 || (dtype != CGPS_F32 && dtype != CGPS_F64)) return fail(CGPS_ERR_UNSUPPORTED, "unsupported d / dtype");
+  *elems = ((3 * d * d + 2 * d + 3) / 4) * 4;
+  return CGPS_OK;
+}
+
+int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void* O_left, int64_t n_loc, int d,
+                      int dtype, void* ws, size_t ws_bytes, void* record_out, double* partial_out, void* stream) {
+  if (bad_common(n_loc, d) || !Rs || (n_loc > 1 && !Os) || !x || !ws || !record_out || !partial_out)
+    return fail(CGPS_ERR_ARG, "cgps_shard_reduce: null pointer or n_loc < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if constexpr (!cgps::tile_supported<T, D>()) {
+      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=5 and fp32 d<=8");
+    } else {
+      int rc = cgps::run_tile_mahal_logdet<T, D>((const T*)Rs, (const T*)Os, (const T*)x, n_loc, (char*)ws, ws_bytes,
+                                                 nullptr, nullptr, (hipStream_t)stream, g_prof_start, g_prof_stop,
+                                                 (const T*)O_left, (T*)record_out, partial_out);
+      g_prof_start = g_prof_stop = nullptr;
+      if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_shard_reduce");
+      return check_launch("shard reduction");
+    }
+  });
+}
+
+int cgps_finish_records(const void* records, size_t record_stride_bytes, const double* partials,
+                        size_t partial_stride_bytes, int64_t P, int64_t rows_per_shard, int64_t N_total, int d,
+                        int dtype, double* out2, int* info, void* stream) {
+  if (P < 1 || d < 1 || !records || !partials || !out2 || !info)
+    return fail(CGPS_ERR_ARG, "cgps_finish_records: null pointer or P < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if constexpr (!cgps::tile_supported<T, D>()) {
+      return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=5 and fp32 d<=8");
+    } else {
+      if (record_stride_bytes % sizeof(T) != 0 || partial_stride_bytes % sizeof(double) != 0 ||
+          record_stride_bytes < cgps::RecordLayout<T, D>::STRIDE * sizeof(T) || partial_stride_bytes < 32)
+        return fail(CGPS_ERR_ARG, "cgps_finish_records: bad record / partial stride");
+      int rc = cgps::run_tile_finish<T, D>((const T*)records, (int64_t)(record_stride_bytes / sizeof(T)), partials,
+                                           (int64_t)(partial_stride_bytes / sizeof(double)), P, rows_per_shard,
+                                           N_total, out2, info, (hipStream_t)stream);
+      if (rc == -1) return fail(CGPS_ERR_ARG, "cgps_finish_records: P outside 1..2048");
+      return check_launch("finish records");
+    }
+  });
+}
+
+}  // extern "C"

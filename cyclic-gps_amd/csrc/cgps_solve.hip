@@ -1,0 +1,240 @@
+// cgps_solve.hip -- halfsolve / backhalfsolve / solve on a stored factor
+// One translation unit of libcgps (include/cgps.h); host code only decides sizes/offsets and
+// enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
+#include "cgps_host.h"
+#include "cgps_tile.h"
+#include "cgps_solve_tile.h"
+
+using namespace cgps_host;
+
+namespace {
+// ---- fused (tiled) substitution sweeps: cgps_solve_tile.h ---------------------------------------
+struct SolvePasses {
+  int np;
+  int first[8];
+  cgps::PassLevels lv[8];
+  int64_t rows[8];
+};
+
+void make_passes(const Layout& L, SolvePasses& P, int wide_lp) {
+  P.np = 0;
+  int lvl = 0;
+  while (lvl < L.nlevels) {
+    const int64_t rows = L.ms[lvl];
+    const int remaining = L.nlevels - lvl;
+    // many tiles: a few levels per pass (every lane busy, few barrier-separated latency
+    // exposures, the factor still read once); few tiles: all ten levels of a tile
+    const int nl = (rows <= cgps::SOLVE_TS) ? remaining
+                   : (rows >= cgps::SOLVE_WIDE_ROWS ? wide_lp : cgps::SOLVE_LP);   // <= SOLVE_LP + 1
+    cgps::PassLevels& pl = P.lv[P.np];
+    pl.nlev = nl;
+    pl.endD = L.offD[lvl + nl];
+    pl.endF = L.offF[lvl + nl < L.nlevels ? lvl + nl : L.nlevels - 1];
+    pl.endG = L.offG[lvl + nl < L.nlevels ? lvl + nl : L.nlevels - 1];
+    for (int j = 0; j < cgps::SOLVE_MAXLEV; ++j) {
+      const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+      pl.offD[j] = L.offD[l]; pl.offF[j] = L.offF[l]; pl.offG[j] = L.offG[l];
+      pl.m[j] = lvl + j < L.nlevels ? L.ms[l] : 0;
+    }
+    P.first[P.np] = lvl;
+    P.rows[P.np] = rows;
+    ++P.np;
+    lvl += nl;
+  }
+}
+
+template <typename T, int D>
+void solve_tile_attributes() {
+  static PerDevice<int> done;
+  done.get([](int) {
+  const int lds = (int)cgps::solve_lds_bytes<T, D>();
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_tile_kernel<T, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_kernel<T, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  return 1;
+  });
+}
+
+template <typename T, int D>
+int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                       size_t ws_bytes, double* mahal_out, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P, cgps::SOLVE_LP_WIDE);
+  solve_tile_attributes<T, D>();
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
+  const size_t lds = cgps::solve_lds_bytes<T, D>();
+  const T* y = y0;
+  const T* owed_in = nullptr;
+  int64_t n_owed = 0, pb = 0;
+  int spt_in = 1;
+  for (int p = 0; p < P.np; ++p) {
+    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    const bool more = (p + 1 < P.np);
+    const int64_t nsurv = n >> P.lv[p].nlev;           // rows of the next pass
+    T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D] surviving rows, then [g][D] owed vectors
+    T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * D : nullptr;
+    hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                       P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+    pb += g;
+    y = yout;
+    owed_in = owed_out;
+    n_owed = g;
+    spt_in = cgps::SOLVE_TS >> P.lv[p].nlev;
+    if (spt_in < 1) spt_in = 1;
+  }
+  if (mahal_out) {
+    double* tmp = partial + 2 * pb;  // one spare slot was reserved
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, tmp);
+    hipMemcpyAsync(mahal_out, tmp, sizeof(double), hipMemcpyDeviceToDevice, st);
+  }
+  return check_launch("halfsolve (tiled)");
+}
+
+template <typename T, int D>
+int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                       size_t ws_bytes, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);
+  if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P, cgps::SOLVE_LP_WIDE);      // (the two sweeps need not use the same passes; 3 / 3 measured best)
+  solve_tile_attributes<T, D>();
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
+                reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};
+  const size_t lds = cgps::solve_lds_bytes<T, D>();
+  const T* xc = nullptr;
+  for (int p = P.np - 1; p >= 0; --p) {
+    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    T* X = (p == 0) ? x : bufs[p & 1];
+    hipLaunchKernelGGL((cgps::backsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                       P.lv[p], ycrr, xc, n, X);
+    xc = X;
+  }
+  return check_launch("backsolve (tiled)");
+}
+
+template <typename T, int D>
+int run_halfsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                            size_t ws_bytes, double* mahal_out, hipStream_t st);
+template <typename T, int D>
+int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                            size_t ws_bytes, hipStream_t st);
+
+template <typename T, int D>
+int run_halfsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws, size_t ws_bytes,
+                  double* mahal_out, hipStream_t st) {
+  if (levelwise_solve_requested()) return run_halfsolve_levelwise<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
+  return run_halfsolve_tile<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
+}
+template <typename T, int D>
+int run_backsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws, size_t ws_bytes,
+                  hipStream_t st) {
+  if (levelwise_solve_requested()) return run_backsolve_levelwise<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
+  return run_backsolve_tile<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
+}
+
+template <typename T, int D>
+int run_halfsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
+                            size_t ws_bytes, double* mahal_out, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
+  const T* y = y0;
+  int64_t pb = 0;
+  for (int l = 0; l < L.nlevels; ++l) {
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* yn = bufs[l & 1];
+    hipLaunchKernelGGL((cgps::halfsolve_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D, y, n,
+                       xcrr + L.offD[l] * D, yn, partial + 2 * pb);
+    pb += nb;
+    y = yn;
+  }
+  if (mahal_out) {
+    double* tmp = partial + 2 * pb;  // one spare slot was reserved
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, tmp);
+    hipMemcpyAsync(mahal_out, tmp, sizeof(double), hipMemcpyDeviceToDevice, st);
+  }
+  return check_launch("halfsolve");
+}
+
+template <typename T, int D>
+int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
+                            size_t ws_bytes, hipStream_t st) {
+  LevelWs w = level_ws(N, D, sizeof(T), false, true);
+  // both ping-pong buffers must hold a level-1 vector here
+  const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);
+  if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+  Layout L;
+  make_layout(N, L);
+  T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
+                reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};
+  const T* xo = nullptr;
+  for (int l = L.nlevels - 1; l >= 0; --l) {
+    const int64_t n = L.ms[l], nb = level_blocks(n);
+    T* X = (l == 0) ? x : bufs[l & 1];
+    hipLaunchKernelGGL((cgps::backsolve_level_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st,
+                       Dp + L.offD[l] * D * D, Fp + L.offF[l] * D * D, Gp + L.offG[l] * D * D,
+                       ycrr + L.offD[l] * D, xo, n, X);
+    xo = X;
+  }
+  return check_launch("backsolve");
+}
+}  // namespace
+
+extern "C" {
+
+int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y,
+                   void* xcrr, void* ws, size_t ws_bytes, double* mahal_out, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !xcrr || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_halfsolve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, (T*)xcrr, (char*)ws, ws_bytes,
+                               mahal_out, (hipStream_t)stream);
+  });
+}
+
+int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* ycrr,
+                   void* x, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !ycrr || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_backsolve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)ycrr, (T*)x, (char*)ws, ws_bytes,
+                               (hipStream_t)stream);
+  });
+}
+
+int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y, void* x,
+               void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_solve: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const size_t crr = align_up((size_t)N * D * sizeof(T));
+    if (ws_bytes < crr) return fail(CGPS_ERR_ARG, "workspace too small");
+    T* xcrr = (T*)ws;
+    int rc = run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, xcrr, (char*)ws + crr,
+                                 ws_bytes - crr, nullptr, (hipStream_t)stream);
+    if (rc != CGPS_OK) return rc;
+    return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, xcrr, (T*)x, (char*)ws + crr,
+                               ws_bytes - crr, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

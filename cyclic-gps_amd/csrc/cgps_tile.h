@@ -32,9 +32,11 @@
 // last REAL row, which is what lets a shard of a larger system (one per GPU) be
 // reduced by the same code to a single record the next shard couples to.
 #pragma once
+#include <mutex>
 #include <type_traits>
 
 #include "cgps_level.h"
+#include "cgps_tile_sizes.h"
 
 namespace cgps {
 
@@ -387,8 +389,6 @@ struct RecordLayout {
   static constexpr int RS = 0, CS = DD, DRA = 2 * DD, YS = 3 * DD, DYA = 3 * DD + D;
 };
 
-// per-block partial results: {sum x^2, sum log pivots, 1 + first failing row or 0, unused}
-constexpr int PARTIAL_STRIDE = 4;
 
 // Thread 0: add what the executed levels owe the row left of the tile to (dRa, dya) (which
 // already hold the streaming stage's share, as negative sums).
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
 }
 
 // {sum, sum, smallest non-zero, 0} over per-block partial results
-__global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __restrict__ partial, int64_t count,
+static __global__ __launch_bounds__(256) void sum_partials4_kernel(const double* __restrict__ partial, int64_t count,
                                                             double* __restrict__ out4) {
   __shared__ double red[2 * 4];
   __shared__ int sf;
@@ -869,33 +869,15 @@ template <typename T, int D> struct TileCfg {
   static constexpr int NG1 = NT1 / LPR;                 // kept rows (= LDS tile slots) per stage-1 workgroup
   static constexpr int64_t ROWS1 = (int64_t)C * NG1;    // rows per stage-1 workgroup
 };
-// TileCfg<T, d>::ROWS1 for a run-time d (workspace sizing)
-inline int64_t tile_rows1(int d) { return d == 8 ? 64 * 256 / 4 : 16 * 256; }
-// Below ~2^19 rows the op is pure latency and stage 1's sequential chain of C - 1 eliminations
-// per lane is most of it.  Small systems therefore take fewer rows per lane: the smallest C of
-// {1, 4, 8, C_full} that keeps the grid within one workgroup per CU (more lanes, shorter chains,
-// the same number of records for the final stage or fewer).
-constexpr int64_t STAGE1_SMALL_TILES = 256;
-inline int stage1_rows_per_lane(int64_t N, int c_full, int lanes) {
-  if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 1) return 1;
-  if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 4) return 4;
-  if (c_full > 8 && N <= STAGE1_SMALL_TILES * lanes * 8) return 8;
-  return c_full;
-}
-inline int64_t tile_cap(int64_t N, int d) { return N / tile_rows1(d) + 2 + STAGE1_SMALL_TILES; }
-
-inline size_t tile_ws_bytes(int64_t N, int d, size_t s) {
-  const int64_t tiles = tile_cap(N, d);
-  const size_t stride = (size_t)(((3 * d * d + 2 * d + 3) / 4) * 4) * s;
-  const size_t pbytes = ((size_t)(2 * tiles + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
-  return pbytes + (((size_t)2 * (tiles + 2) * stride + 255) & ~(size_t)255);
-}
-
+constexpr int TILE_MAX_DEVICES = 64;
 template <typename T, int D>
 void tile_set_attributes() {
   using Cfg = TileCfg<T, D>;
-  static bool done = false;
-  if (done) return;
+  static std::once_flag once[TILE_MAX_DEVICES];     // attributes belong to a device, not to the process
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= TILE_MAX_DEVICES) dev = 0;
+  std::call_once(once[dev], [] {
   const int lds1 = (int)stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = (int)stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
   if constexpr (Cfg::LPR > 1)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>),
@@ -918,7 +900,7 @@ void tile_set_attributes() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-  done = true;
+  });
 }
 
 // The fused pipeline.  Whole system: shard_record == nullptr, results in out2 / info.

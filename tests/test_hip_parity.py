@@ -175,7 +175,8 @@ def test_not_positive_definite_raises():
     (2 ** 22, 8, torch.float32, 2e-5),      # BASELINE config 3
     (2 ** 20 + 12345, 4, torch.float64, 1e-10),
     (2 ** 21 + 1, 5, torch.float64, 1e-10),
-], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64"])
+    (2 ** 24, 4, torch.float64, 1e-10),     # BASELINE config 4 as ONE system on one GPU (three-launch record path)
+], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64", "c4_N2^24_d4_f64"])
 def test_full_size_closed_form(N, d, dtype, rtol):
     """Size-independent properties at the benchmark sizes: J = L L^T with L block
     bidiagonal, so log|J| and the planted solution x_true are known in closed form."""

@@ -154,3 +154,32 @@ def test_sharded_plan_world1_on_gpu():
     out = plan.run().cpu().numpy()
     np.testing.assert_allclose(out, [mahal_true, logdet_true], rtol=1e-10)
     assert int(plan.ops.info.item()) == 0
+
+
+@pytest.mark.gpu
+def test_config4_as_eight_shards_on_one_gpu():
+    """BASELINE config 4 (N = 2^24, d = 4, fp64) in the shape the 8-GPU run has it: eight shards of
+    2^21 rows, each reduced by cgps_shard_reduce (with its left coupling), the eight records
+    finished by cgps_finish_records -- all on one GPU, against the closed form and against the
+    same system reduced whole by cgps_mahal_logdet."""
+    import cyclic_gps.cyclic_reduction as cr
+    n, d, parts = 2 ** 24, 4, 8
+    dev = torch.device("cuda")
+    Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, device="cuda")
+    mahal_true = float((x_true * b).sum())
+    del x_true
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    assert all(hi - lo == 2 ** 21 for lo, hi in bounds)
+    rec_bytes, msg_bytes = sharded.message_layout(d, torch.float64)
+    recv = torch.zeros(parts * msg_bytes, dtype=torch.uint8, device=dev)
+    ops = sharded.HipShardOps(2 ** 21, d, torch.float64, dev)
+    for r, (sR, sO, sx, Ol) in enumerate(_split(Rs, Os, b, bounds)):
+        ops.shard_reduce(sR, sO, sx, None if Ol is None else Ol.contiguous(), recv[r * msg_bytes:(r + 1) * msg_bytes],
+                         rec_bytes)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)
+    ops.finish(recv, parts, rec_bytes, msg_bytes, 2 ** 21, n, out)
+    got = out.cpu().numpy()
+    assert int(ops.info.item()) == 0
+    np.testing.assert_allclose(got, [mahal_true, logdet], rtol=1e-10)
+    m, ld = cr.mahal_and_det(Rs, Os, b)                     # the same system as ONE shard
+    np.testing.assert_allclose(got, [float(m), float(ld)], rtol=1e-12)
