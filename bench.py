@@ -8,9 +8,12 @@ cyclic_reduction.py:380-438) of one synthetic SPD block-tridiagonal system whose
 blocks are already resident in HBM, called through the C ABI (include/cgps.h).
 
 N = 1 : BASELINE.json configs[1] -- N_rows = 2^20, d = 4, fp64.
-N > 1 : one system of N * 2^20 block rows, time axis sharded over the ranks
-        (2^20 rows per GPU: weak scaling); each rank reduces its shard locally and
-        ONE all-gather of the shard-boundary blocks finishes the reduction.
+N > 1 : BASELINE.json configs[3] -- ONE system of 2^24 block rows, d = 4, fp64, time axis
+        sharded over the N ranks (2^24 / N rows per GPU: STRONG scaling); each rank reduces its
+        shard locally and ONE all-gather of the shard-boundary blocks finishes the reduction.
+        Rank 0 also times the same 2^24-row system on its GPU alone (outside the timed
+        region) so that the line carries the speed-up; the weak-scaling point (2^20 rows per
+        GPU) goes to `extras`.
 `value` is the whole-job algorithmic GB/s (the "log-det GB/s" of the metric:
 compulsory bytes B_A = ((2n-1) d^2 + n d) s + 2s of SURVEY.md 8(d), divided by
 the wall time); solves/s is reported beside it.
@@ -38,7 +41,10 @@ for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests"
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:36
-ROWS_PER_GPU = 1 << 20
+ROWS_PER_GPU = 1 << 20         # config 2 (and the weak-scaling point)
+ROWS_CONFIG4 = 1 << 24         # config 4: ONE system, sharded over the GPUs
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"
+KERNEL_STATS_FILE = "r01_kernel_stats_headline_v9.csv"
 D = 4
 DTYPE = torch.float64
 
@@ -53,21 +59,56 @@ def make_system(n, d, dtype, device, seed=1234):
     return _util.conditioned_system(n, d, dtype=dtype, seed=seed, device=device)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _mkl_version():
+    try:
+        for line in torch.__config__.show().splitlines():
+            if "Math Kernel Library" in line or "MKL" in line and "Version" in line:
+                return line.strip(" -")
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(n, d, dtype, reps=3):
-    """The oracle (port of the reference's op sequence) on the host cores, same workload."""
+    """The oracle (port of the reference's op sequence) on the host cores, same workload
+    (all cores and one thread; nproc, CPU model, torch / MKL versions)."""
     from oracle import cr_oracle
     Rs, Os, b, _, _ = make_system(n, d, dtype, "cpu")
     cores = torch.get_num_threads()
+
+    def best_of(k):
+        best = float("inf")
+        for _ in range(k):
+            t0 = time.perf_counter()
+            cr_oracle.mahal_and_det(Rs, Os, b)
+            best = min(best, time.perf_counter() - t0)
+        return best
     cr_oracle.mahal_and_det(Rs[: n // 8], Os[: n // 8 - 1], b[: n // 8])       # warm-up
-    best = float("inf")
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        cr_oracle.mahal_and_det(Rs, Os, b)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": 1.0 / best, "unit": "solves/s", "seconds": best,
-            "GBps": algorithmic_bytes(n, d, Rs.element_size()) / best / 1e9, "cores": cores, "kind": "port",
-            "sample": "full workload N=%d d=%d %s, min of %d runs after a 1/8-size warm-up; torch %s"
-                      % (n, d, str(dtype).replace("torch.", ""), reps, torch.__version__)}
+    best = best_of(reps)
+    torch.set_num_threads(1)
+    try:
+        cr_oracle.mahal_and_det(Rs[: n // 8], Os[: n // 8 - 1], b[: n // 8])
+        best1 = best_of(2)
+    finally:
+        torch.set_num_threads(cores)
+    nbytes = algorithmic_bytes(n, d, Rs.element_size())
+    return {"value": 1.0 / best, "unit": "solves/s", "seconds": best, "GBps": nbytes / best / 1e9, "cores": cores,
+            "kind": "port",
+            "one_thread": {"value": 1.0 / best1, "seconds": best1, "GBps": nbytes / best1 / 1e9, "cores": 1},
+            "nproc": os.cpu_count(), "cpu_model": _cpu_model(), "torch": torch.__version__, "mkl": _mkl_version(),
+            "sample": "full workload N=%d d=%d %s: min of %d runs on %d threads and min of 2 runs on 1 thread "
+                      "(torch.set_num_threads), each after a 1/8-size warm-up"
+                      % (n, d, str(dtype).replace("torch.", ""), reps, cores)}
 
 
 def _time_cuda(fn, reps, warm=2):
@@ -230,6 +271,24 @@ def extra_measurements(dev):
     return out
 
 
+def _timed_steps(step, steps, warmup, barrier):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def _file_sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,7 +297,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (Op B / config 3 / 2^24) numbers")
     ap.add_argument("--levelwise", action="store_true", help="time the one-launch-per-level form instead")
-    ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="block rows per GPU")
+    ap.add_argument("--rows", type=int, default=0,
+                    help="block rows of the WHOLE system (default: 2^20 on one GPU = config 2; 2^24 on several = config 4)")
     ap.add_argument("--d", type=int, default=D)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     args = ap.parse_args()
@@ -259,7 +319,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    d, rows = args.d, args.rows
+    d = args.d
 
     from cyclic_gps import _hip
     lib = _hip.lib()
@@ -276,49 +336,51 @@ def main():
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=dev)
-    n_total = rows * world
-
-    # ---- synthetic system, resident in HBM ------------------------------------------------
-    if not sharded_mode:
-        Rs, Os, b, x_true, logdet_true = make_system(rows, d, dtype, dev)
-        mahal_true = float((x_true.double() * b.double()).sum())
+    # the workload: config 2 on one GPU; config 4 (ONE 2^24-row system, strong scaling) on several
+    n_total = args.rows if args.rows > 0 else (ROWS_CONFIG4 if world > 1 else ROWS_PER_GPU)
+    if sharded_mode:
+        lo, hi = sharded.shard_bounds(n_total, world, rank)
+        rows = hi - lo
     else:
-        Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(n_total, d, dtype, dev, rank, world)
-    out = torch.zeros(2, dtype=torch.float64, device=dev)
-    info = torch.zeros(1, dtype=torch.int32, device=dev)
-    ws, ws_bytes = _hip.workspace(rows + 1, d, dtype, _hip.OP_MAHAL_LOGDET, dev)
-    stream = torch.cuda.current_stream()
-    sp = ctypes.c_void_p(stream.cuda_stream)
-    fn = lib.cgps_mahal_logdet_levelwise if args.levelwise else lib.cgps_mahal_logdet
-    dcode = _hip.dtype_code(dtype)
-
-    if not sharded_mode:
-        def step():
-            _hip.check(fn(_hip.ptr(Rs), _hip.ptr(Os), _hip.ptr(b), rows, d, dcode, _hip.ptr(ws), ws_bytes,
-                          _hip.ptr(out), _hip.ptr(info), sp))
-    else:
-        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world)
-        info = plan.ops.info
-
-        def step():
-            plan.run(out)
+        rows = n_total
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    # ---- synthetic system, resident in HBM ------------------------------------------------
+    stream = torch.cuda.current_stream()
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    fn = lib.cgps_mahal_logdet_levelwise if args.levelwise else lib.cgps_mahal_logdet
+    dcode = _hip.dtype_code(dtype)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)
 
-    # ---- timed region: exactly K steps ------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def whole_system_step(n):
+        """(step, info, mahal_true, logdet_true) for ONE n-row system on this GPU alone."""
+        Rs_, Os_, b_, x_true_, logdet_ = make_system(n, d, dtype, dev)
+        mahal_ = float((x_true_.double() * b_.double()).sum())
+        del x_true_
+        info_ = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_, ws_bytes_ = _hip.workspace(n + 1, d, dtype, _hip.OP_MAHAL_LOGDET, dev)
+
+        def step_():
+            _hip.check(fn(_hip.ptr(Rs_), _hip.ptr(Os_), _hip.ptr(b_), n, d, dcode, _hip.ptr(ws_), ws_bytes_,
+                          _hip.ptr(out), _hip.ptr(info_), sp))
+        return step_, info_, mahal_, logdet_
+
+    if not sharded_mode:
+        step, info, mahal_true, logdet_true = whole_system_step(rows)
+    else:
+        Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(n_total, d, dtype, dev, rank, world)
+        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world)
+        info = plan.ops.info
+
+        def step():
+            plan.run(out)
+
+    # ---- timed region: W warm-up steps, then exactly K steps ----------------------------------
+    elapsed = _timed_steps(step, args.steps, args.warmup, barrier)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -349,25 +411,64 @@ def main():
     assert int(info.item()) == 0, "library reported a non-positive-definite block"
     assert rel_ld < tol and rel_m < tol * 10, ("result mismatch", rel_ld, rel_m)
 
-    if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
     s = 8 if dtype == torch.float64 else 4
     t_step = elapsed / args.steps
     b_total = algorithmic_bytes(n_total, d, s)
     b_kernel = algorithmic_bytes(rows, d, s)     # what ONE launch of the dominant kernel streams (one shard)
+
+    # ---- several GPUs: the single-GPU time of the SAME system (speed-up) and the weak-scaling point,
+    # outside the timed region ----------------------------------------------------------------
+    scaling_extras = None
+    if sharded_mode and world > 1:
+        scaling_extras = {}
+        del plan, Rs, Os, b
+        torch.cuda.empty_cache()
+        k1 = max(3, min(10, args.steps))
+        if rank == 0:
+            try:
+                step1, info1, m1, ld1 = whole_system_step(n_total)
+                e1 = _timed_steps(step1, k1, 2, torch.cuda.synchronize) / k1
+                r1 = out.cpu()
+                scaling_extras["single_gpu_same_system"] = {
+                    "rows": n_total, "ms_per_step": e1 * 1e3, "GBps": b_total / e1 / 1e9,
+                    "logdet_rel_err": abs(float(r1[1]) - ld1) / abs(ld1), "steps": k1}
+                scaling_extras["speedup_vs_single_gpu"] = e1 / t_step
+                del step1
+            except Exception as e:
+                scaling_extras["single_gpu_same_system"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+        barrier()
+        try:      # weak-scaling point: 2^20 rows per GPU, one system of world * 2^20 rows
+            nw = ROWS_PER_GPU * world
+            Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(nw, d, dtype, dev, rank, world)
+            planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, nw, rank, world)
+            ew = _timed_steps(lambda: planw.run(out), args.steps, args.warmup, barrier)
+            tw = torch.tensor([ew], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            ew = float(tw.item()) / args.steps
+            rw = out.cpu()
+            scaling_extras["weak_2^20_rows_per_gpu"] = {
+                "rows_total": nw, "ms_per_step": ew * 1e3, "GBps": algorithmic_bytes(nw, d, s) / ew / 1e9,
+                "logdet_rel_err": abs(float(rw[1]) - ldw) / abs(ldw)}
+        except Exception as e:
+            scaling_extras["weak_2^20_rows_per_gpu"] = {"error": repr(e)[:200]}
+
+    if rank != 0:
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    cfgname = "config 4" if n_total == ROWS_CONFIG4 else ("config 2" if n_total == ROWS_PER_GPU else "custom size")
     line = {
-        "metric": "block-tridiag solve+log-det (mahal_and_det) algorithmic GB/s vs HBM roofline, N=2^20 d=4 per GPU; "
-                  "solves/s alongside",
+        "metric": "block-tridiag solve+log-det (mahal_and_det) algorithmic GB/s vs HBM roofline, N=2^20 d=4 on one GPU, "
+                  "N=2^24 d=4 time-axis sharded on several; solves/s alongside",
         "value": b_total / t_step / 1e9, "unit": "GB/s",
         "solves_per_s": 1.0 / t_step,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f64" if dtype == torch.float64 else "f32", "data": "synthetic",
-        "config": {"workload": "mahal_and_det on one SPD block-tridiagonal system, N=%d block rows (%d per GPU), d=%d, "
-                               "conditioned bidiagonal-factor generator seed 1234" % (n_total, rows, d),
-                   "rows_per_gpu": rows, "d": d, "algorithmic_bytes": b_total,
+        "config": {"workload": "BASELINE %s: mahal_and_det on ONE SPD block-tridiagonal system, N=%d block rows (%d per "
+                               "GPU), d=%d, conditioned bidiagonal-factor generator seed 1234" % (cfgname, n_total, rows, d),
+                   "rows_total": n_total, "rows_per_gpu": rows, "d": d, "algorithmic_bytes": b_total,
                    "parallelism": "time-axis shards x%d, one all-gather of boundary blocks" % world if world > 1
                    else "single GPU",
                    "algo": "levelwise" if args.levelwise else "tile-fused"},
@@ -380,18 +481,26 @@ def main():
                      "ms_per_step_with_event_hooks": elapsed_with_events / args.steps * 1e3},
         "check": {"logdet_rel_err": rel_ld, "mahal_rel_err": rel_m},
     }
+    if scaling_extras is not None:
+        line["extras"] = scaling_extras
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
     # the number comes from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, calibrated as the guide says)
+    # (profiles/<round>_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, calibrated as the guide says).
+    # The file names the kernel sources it was measured on; when they have changed since, the figure
+    # is reported as stale instead of being passed off as current.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+        if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise and world == 1:
             line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json"
+            line["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
+            sha = pmc.get("kernel_source_sha16")
+            if sha is not None:
+                cur = {f: _file_sha16(os.path.join(ROOT, "cyclic-gps_amd", "csrc", f)) for f in sha}
+                line["roofline"]["traffic_stale"] = cur != sha
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats
             # summary of this command (HIP events around a launch also see its dispatch latency)
             import csv
-            prof = "profiles/r01_kernel_stats_headline_v9.csv"
+            prof = "profiles/" + KERNEL_STATS_FILE
             for r in csv.DictReader(open(os.path.join(ROOT, prof))):
                 if "chunk_reduce_kernel" in r["Name"]:
                     line["roofline"]["kernel_avg_us_rocprofv3"] = float(r["AverageNs"]) / 1e3

@@ -32,7 +32,10 @@
 // last REAL row, which is what lets a shard of a larger system (one per GPU) be
 // reduced by the same code to a single record the next shard couples to.
 #pragma once
+#include <cstdlib>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <type_traits>
 
 #include "cgps_level.h"
@@ -240,7 +243,12 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 // it (16 eliminations for 256 threads, 32 for 512): measured 0.9-1.2 us against 1.9-2.6 us for a
 // role-split pass, while two such passes are no faster than one role-split pass.
 
-template <typename T, int D, int NTHR>
+// MW: a level runs on the matrix cores when it has at most MW * NTHR / 16 eliminations (MW = 1, 2
+// or 4 of them carried side by side per 16-lane group), role-split otherwise.
+#ifndef CGPS_MFMA_WIDE
+#define CGPS_MFMA_WIDE 1
+#endif
+template <typename T, int D, int NTHR, int MW = CGPS_MFMA_WIDE>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
                                        long long* stamps = nullptr) {
   int stamp_pass = 0;
@@ -258,10 +266,16 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
     const int M = (K + 1) / s, h = s >> 1;
     const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
     if constexpr (std::is_same<T, double>::value && D == 4) {
-      // narrow level: sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h)
-      if (n_elim <= NTHR / 16) {
-        tile_cr_level_mfma<NTHR>(t, K, M, s, pl, mah, fail);
-        continue;
+      // sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h); a level with more
+      // eliminations than the workgroup has 16-lane groups carries 2 or 4 of them per group, side
+      // by side (independent dependency chains that fill each other's latency slots)
+      constexpr int PER = NTHR / 16;
+      if (n_elim <= PER) { tile_cr_level_mfma<NTHR, 1>(t, K, M, s, pl, mah, fail); continue; }
+      if constexpr (MW >= 2) {
+        if (n_elim <= 2 * PER) { tile_cr_level_mfma<NTHR, 2>(t, K, M, s, pl, mah, fail); continue; }
+      }
+      if constexpr (MW >= 4) {
+        if (n_elim <= 4 * PER) { tile_cr_level_mfma<NTHR, 4>(t, K, M, s, pl, mah, fail); continue; }
       }
     }
 #pragma unroll 1
@@ -379,6 +393,58 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
   return levels;
 }
 
+// ---- in-launch hand-off of the stage-1 records to the workgroup that arrives last -------------
+// Records and partial results are stored WRITE-THROUGH (agent-scope relaxed atomic stores =
+// global_store ... sc1): they reach the memory side without a release fence, so that the last
+// stage-1 workgroup of a launch can pick them up inside the same launch (fold_final below) as
+// well as a later kernel can.
+template <typename T>
+__device__ __forceinline__ void store_wt(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The matching loads: agent-scope relaxed atomic loads (global_load ... sc1) are served past this
+// CU's L1 from the coherent memory side, so a workgroup that learnt from the value its arrival
+// atomic returned that every producer has stored (and drained) may read the handed-off bytes
+// with them without an acquire fence -- provided EVERY load of those bytes is such a load
+// (MI355X guide, inter-workgroup visibility: hand-offs measured with sc1 loads, first row:
+// one lane per storing workgroup adds to ONE counter, the last adder told by the returned value,
+// hipMalloc memory, one workgroup per CU, 8-byte stores and loads).  COH = false: plain loads.
+template <bool COH, typename T>
+__device__ __forceinline__ T load_coh(const T* p) {
+  if constexpr (COH) return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+// 16 bytes as a Vec16<T>::type; coherent form: two 8-byte loads
+template <bool COH, typename T>
+__device__ __forceinline__ typename Vec16<T>::type load16_coh(const T* p) {
+  using V = typename Vec16<T>::type;
+  if constexpr (COH) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<T*>(p));
+    unsigned long long w[2];
+    w[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    V v;
+    __builtin_memcpy(&v, w, 16);
+    return v;
+  } else {
+    return *reinterpret_cast<const V*>(p);
+  }
+}
+
+// Arrival counters of the folded final stage.  They live in the library's own device data (zero
+// when the code object is loaded, touched by nothing else) rather than in the caller's
+// workspace, whose contents are arbitrary before a call and which other entry points use as
+// scratch.  A counter is incremented with a wrapping atomic (atomicInc: old >= limit ? 0 : old + 1),
+// so the arrival that completes the count also puts it back to 0: no per-call memset, no reset
+// store, and a replayed graph launch finds it clean.  The host maps each workspace it has seen to
+// one slot (fold_slot_for): two launches may be in flight at the same time only with different
+// workspaces (include/cgps.h), hence with different counters.
+constexpr int FOLD_SLOTS = 1024;
+constexpr int FOLD_GROUP = 16;              // stage-1 records per group (fold_final, below)
+constexpr int FOLD_MAX_GROUPS = 16;         // <= 256 stage-1 workgroups
+// [slot][0]: arrivals of the group leaders; [slot][1 + g]: arrivals of group g's workgroups
+static __device__ unsigned int g_fold_counter[FOLD_SLOTS][1 + FOLD_MAX_GROUPS];
+
 // A record = what a tile leaves behind: its boundary row (Rs, ys), that row's coupling
 // to the previous tile's boundary row (Cs = J[this, previous]) and the additive update
 // (dRa, dya) for the previous tile's boundary row.
@@ -415,12 +481,12 @@ __device__ __forceinline__ void write_partial(double mah, double logp, int failr
   block_sum2<NT>(mah, logp, red);      // contains a barrier when NT > 64
   if constexpr (NT <= 64) __syncthreads();
   if (threadIdx.x == 0) {
-    double* p = partial + PARTIAL_STRIDE * (size_t)blockIdx.x;
+    double* p = partial;                 // this workgroup's slot
     const int f = *sfail;
-    p[0] = mah;
-    p[1] = logp;
-    p[2] = (f == 0x7fffffff) ? 0.0 : (double)f;
-    p[3] = 0.0;
+    store_wt(p + 0, mah);
+    store_wt(p + 1, logp);
+    store_wt(p + 2, (f == 0x7fffffff) ? 0.0 : (double)f);
+    store_wt(p + 3, 0.0);
   }
 }
 
@@ -531,13 +597,13 @@ __device__ __forceinline__ void reduce_staged_tile_and_emit(LdsTile<T, D>& t, in
       dra -= elem(t.R, slot);
       dyv -= t.y[slot * D + i];
     }
-    T* r = rec_out + (size_t)blockIdx.x * RL::STRIDE;
-    r[RL::RS + tid] = elem(t.R, n_real - 1);
-    r[RL::CS + tid] = elem(t.Oc, 0);
-    r[RL::DRA + tid] = dra;
+    T* r = rec_out;                      // this tile's record
+    store_wt(r + RL::RS + tid, elem(t.R, n_real - 1));
+    store_wt(r + RL::CS + tid, elem(t.Oc, 0));
+    store_wt(r + RL::DRA + tid, dra);
     if (j == 0) {
-      r[RL::YS + i] = t.y[(n_real - 1) * D + i];
-      r[RL::DYA + i] = dyv;
+      store_wt(r + RL::YS + i, t.y[(n_real - 1) * D + i]);
+      store_wt(r + RL::DYA + i, dyv);
     }
   }
 }
@@ -569,11 +635,28 @@ template <typename T, int D> constexpr int stage1_min_waves() {
 // at most one workgroup per CU: the extra four waves stream nothing, they are a second set of
 // role waves, so that the 128 eliminations of the tile's first level take one pass instead of two
 // (and the 32 of its third go to the matrix cores).
-template <typename T, int D, int C, int NT, int NW = NT>
+// FOLD: the workgroup whose record arrives last also runs the final reduction of
+// all the launch's records and writes out2 / info: no second launch, no cold start of a lone final
+// workgroup.  For grids of at most NT workgroups (one final tile) with NW = 2 NT threads, which is
+// what the final reduction wants.
+struct FoldArgs {
+  int slot;                        // this launch's arrival counters: g_fold_counter[slot][..]
+  void* group_records;             // [groups] records of the second level (workspace)
+  double* out2;
+  int* info;
+};
+template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL = false>
+__device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
+                                                   int rc, T* __restrict__ rout, double* __restrict__ partial_out,
+                                                   const double* __restrict__ partial_in, int64_t n_partial,
+                                                   double* __restrict__ out2, int* __restrict__ info,
+                                                   int64_t rows_per_record, int64_t N, int64_t rstride, int64_t pstride);
+template <typename T, int D, int C, int NT, int NW = NT, bool FOLD = false>
 __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
                                                           const T* __restrict__ Oleft,
-                                                          T* __restrict__ rec, double* __restrict__ partial) {
+                                                          T* __restrict__ rec, double* __restrict__ partial,
+                                                          FoldArgs fold) {
   // Oleft: J[row 0 of this shard, last row of the previous shard], or nullptr when row 0 is the
   // first row of the whole system.
   constexpr int DD = D * D;
@@ -642,10 +725,70 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
 
   int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
   const int n_real = nreal64 > NT ? NT : (int)nreal64;
-  reduce_tile_and_emit<T, D, NW>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec, pl, mah, fail);
+  reduce_tile_and_emit<T, D, NW>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec + (size_t)blockIdx.x * RecordLayout<T, D>::STRIDE,
+                                 pl, mah, fail);
   int64_t frow = r0 < N ? r0 : N - 1;
-  write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial, sm.red, sm.sfail);
+  write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
+  if constexpr (FOLD) {
+    static_assert(NW == 2 * NT, "fold_final runs the record stages with the wide workgroup");
+    // Two levels inside the launch.  The workgroups of a GROUP of FOLD_GROUP consecutive tiles
+    // arrive on the group's counter; the one that arrives last reduces the group's records to
+    // one (four narrow levels, ~7 KB pulled through one CU) and arrives on the launch's counter;
+    // the group leader that arrives last there reduces the <= 16 group records, eliminates the
+    // last row and writes out2 / info.  Against ONE workgroup taking all 256 records: the 115 KB
+    // copy through a single CU (~3 us) becomes sixteen parallel 7 KB copies, and the two widest
+    // levels (128 and 64 eliminations, 2.3 + 1.3 us) become narrow ones (0.85 us).
+    // Hand-off (MI355X guide, inter-workgroup communication): every store of a record or
+    // partial result is a write-through store issued by wave 0; wave 0 drains them, ONE lane
+    // arrives with one returning agent-scope atomic; the last arriver reads the handed-off bytes
+    // with coherent (sc1) loads ONLY (COH) -- or, for block sizes whose copy is not vectorised,
+    // takes an agent-scope acquire and uses plain loads; the workgroup barrier holds the other
+    // waves until the arrival has returned (and the invalidate has completed).
+    constexpr bool COH = (D * D) % Vec16<T>::N == 0;
+    using RL = RecordLayout<T, D>;
+    int* last_flag = sm.sfail + 1;
+    const unsigned grp = blockIdx.x / FOLD_GROUP, ngrp = (gridDim.x + FOLD_GROUP - 1) / FOLD_GROUP;
+    const unsigned gsize = (grp + 1 < ngrp) ? (unsigned)FOLD_GROUP : gridDim.x - grp * FOLD_GROUP;
+    auto arrive = [&](unsigned int* ctr, unsigned expected) {
+      if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+          const bool last = atomicInc(ctr, expected - 1u) == expected - 1u;
+          *last_flag = last ? 1 : 0;
+          if (!COH && last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+      }
+      __syncthreads();
+      return *last_flag != 0;                    // workgroup-uniform
+    };
+    T* grec = reinterpret_cast<T*>(fold.group_records);
+    double* gpartial = partial + PARTIAL_STRIDE * (size_t)gridDim.x;       // the groups' partial results
+    if (arrive(&g_fold_counter[fold.slot][1 + grp], gsize)) {
+      record_reduce_body<T, D, FOLD_GROUP, NW, false, COH>(smem, grp, rec, (int64_t)gridDim.x, 1, grec, gpartial,
+                                                           (const double*)nullptr, (int64_t)0, (double*)nullptr,
+                                                           (int*)nullptr, (int64_t)C * NT, N, (int64_t)RL::STRIDE,
+                                                           (int64_t)PARTIAL_STRIDE);
+      if (arrive(&g_fold_counter[fold.slot][0], ngrp)) {
+        record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr, (double*)nullptr,
+                                                                 partial, (int64_t)gridDim.x + ngrp, fold.out2, fold.info,
+                                                                 (int64_t)C * NT * FOLD_GROUP, N, (int64_t)RL::STRIDE,
+                                                                 (int64_t)PARTIAL_STRIDE);
+      }
+    }
+  }
 }
+
+// dev-only wall-clock stamps of the final reduction (dev_bench.hip defines CGPS_FIN_STAMPS; no stamp
+// executes in the library build)
+#ifdef CGPS_FIN_STAMPS
+static __device__ long long g_fin_stamps[16];
+#define CGPS_FSTAMP(k) do { if (FINAL && threadIdx.x == 0) g_fin_stamps[k] = wall_clock64(); } while (0)
+#else
+#define CGPS_FSTAMP(k) do { } while (0)
+#endif
 
 // ---- stage 3 -----------------------------------------------------------------------------
 // Records in -> records out (FINAL = false), or -> out2 = {mahal, logdet} and info (FINAL =
@@ -682,6 +825,13 @@ __device__ __forceinline__ void load_record_row(const T* __restrict__ rin, int64
   }
 }
 
+template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL>
+__device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
+                                                   int rc, T* __restrict__ rout, double* __restrict__ partial_out,
+                                                   const double* __restrict__ partial_in, int64_t n_partial,
+                                                   double* __restrict__ out2, int* __restrict__ info,
+                                                   int64_t rows_per_record, int64_t N, int64_t rstride, int64_t pstride);
+
 template <typename T, int D, int NTILE, int NT, bool FINAL>
 __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__ rin, int64_t n, int rc,
                                                            T* __restrict__ rout, double* __restrict__ partial_out,
@@ -689,12 +839,25 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
                                                            double* __restrict__ out2, int* __restrict__ info,
                                                            int64_t rows_per_record, int64_t N, int64_t rstride,
                                                            int64_t pstride) {
-  using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  record_reduce_body<T, D, NTILE, NT, FINAL>(smem, blockIdx.x, rin, n, rc, rout, partial_out, partial_in, n_partial, out2,
+                                             info, rows_per_record, N, rstride, pstride);
+}
+
+// tile_index: which NTILE * rc records this workgroup takes (blockIdx.x of record_reduce_kernel; 0
+// when the last stage-1 workgroup of a launch runs the final reduction itself, fold_final)
+template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL>
+__device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
+                                                   int rc, T* __restrict__ rout, double* __restrict__ partial_out,
+                                                   const double* __restrict__ partial_in, int64_t n_partial,
+                                                   double* __restrict__ out2, int* __restrict__ info,
+                                                   int64_t rows_per_record, int64_t N, int64_t rstride, int64_t pstride) {
+  using RL = RecordLayout<T, D>;
   StageSmem<T, D, NTILE, NT> sm(smem);
   const int tid = threadIdx.x;
+  CGPS_FSTAMP(0);
   if (tid == 0) *sm.sfail = 0x7fffffff;
-  const int64_t w0 = (int64_t)blockIdx.x * NTILE * rc;    // first record of this tile
+  const int64_t w0 = (int64_t)tile_index * NTILE * rc;    // first record of this tile
   int64_t wend = w0 + (int64_t)NTILE * rc;
   if (wend > n) wend = n;
   const int64_t wlast = wend - 1;                         // its last one (kept; its update is deferred)
@@ -711,56 +874,95 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
   if (FINAL) {
     for (int64_t i = tid; i < n_partial; i += NT) {
       const double* p = partial_in + pstride * i;
-      pre_mah += p[0];
-      pre_logp += p[1];
-      if (p[2] != 0.0 && (int)p[2] < pre_fail) pre_fail = (int)p[2];
+      const double p0 = load_coh<INL>(p), p1 = load_coh<INL>(p + 1), p2 = load_coh<INL>(p + 2);
+      pre_mah += p0;
+      pre_logp += p1;
+      if (p2 != 0.0 && (int)p2 < pre_fail) pre_fail = (int)p2;
     }
   }
   constexpr int VN = Vec16<T>::N;
-  if ((D * D) % VN == 0 && rc == 1 && rstride % VN == 0) {
+  static_assert(!INL || (D * D) % VN == 0, "the in-launch form reads every handed-off byte with coherent loads: vector path only");
+  bool staged = false;
+  if constexpr ((D * D) % VN == 0) {
+  if (INL || (rc == 1 && rstride % VN == 0)) {
+    staged = true;
     // One record per row: no sequential eliminations first, so the rows go straight into the LDS
     // tile, all NT threads copying 16-byte granules (consecutive threads = consecutive granules of
     // a record) instead of NTILE lanes walking one record each with 64 lines per instruction.
     // Row w = Rs[w] + dRa[w+1], y = ys[w] + dya[w+1] (not for the tile's last row), coupling Cs[w].
+    // Every load of the copy is requested before the first one is waited for (a loop that loads,
+    // waits and stores per iteration exposes one memory round trip per iteration: six of them
+    // measured ~5 us of the lone final workgroup's 16).
     using V = typename Vec16<T>::type;
     using LT = LdsTile<T, D>;
     constexpr int G = (D * D) / VN;
-    for (int gi = tid; gi < n_real * G; gi += NT) {
-      const int slot = gi / G, g = gi % G;
+    constexpr int ITG = (NTILE * G + NT - 1) / NT, ITY = (NTILE * D + NT - 1) / NT;
+    V ga[ITG], gc[ITG], gu[ITG];
+    T yv[ITY], yu[ITY];
+    const V vzero = V{};
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int gi = tid + it * NT;
+      const bool ok = gi < n_real * G;
+      const int slot = ok ? gi / G : 0, g = ok ? gi % G : 0;
       const int64_t w = w0 + slot;
       const T* r = rin + (size_t)w * rstride;
-      V a = *reinterpret_cast<const V*>(r + RL::RS + g * VN);
-      const V c = *reinterpret_cast<const V*>(r + RL::CS + g * VN);
-      if (w != wlast) {
-        const V u = *reinterpret_cast<const V*>(r + rstride + RL::DRA + g * VN);
-        T* ae = reinterpret_cast<T*>(&a);
-        const T* ue = reinterpret_cast<const T*>(&u);
+      ga[it] = load16_coh<INL>(r + RL::RS + g * VN);
+      gc[it] = load16_coh<INL>(r + RL::CS + g * VN);
+      gu[it] = (ok && w != wlast) ? load16_coh<INL>(r + rstride + RL::DRA + g * VN) : vzero;
+    }
+#pragma unroll
+    for (int it = 0; it < ITY; ++it) {
+      const int vi = tid + it * NT;
+      const bool ok = vi < n_real * D;
+      const int slot = ok ? vi / D : 0, i = ok ? vi % D : 0;
+      const int64_t w = w0 + slot;
+      const T* r = rin + (size_t)w * rstride;
+      yv[it] = load_coh<INL>(r + RL::YS + i);
+      yu[it] = (ok && w != wlast) ? load_coh<INL>(r + rstride + RL::DYA + i) : T(0);
+    }
+    // the tile's own share for the row left of it: one element per lane of the last wave
+    constexpr int OWN_IT = (D * D + D + 63) / 64;
+    T own[OWN_IT];
+    const int oi = tid - (NT - 64);
+#pragma unroll
+    for (int it = 0; it < OWN_IT; ++it) {
+      const int q = oi + 64 * it;
+      own[it] = (oi >= 0 && q < D * D + D)
+                    ? load_coh<INL>(rin + (size_t)w0 * rstride + (q < D * D ? RL::DRA + q : RL::DYA + (q - D * D))) : T(0);
+    }
+    CGPS_FSTAMP(1);
+#pragma unroll
+    for (int it = 0; it < ITG; ++it) {
+      const int gi = tid + it * NT;
+      if (gi < n_real * G) {
+        const int slot = gi / G, g = gi % G;
+        T* ae = reinterpret_cast<T*>(&ga[it]);
+        const T* ue = reinterpret_cast<const T*>(&gu[it]);
 #pragma unroll
         for (int q = 0; q < VN; ++q) ae[q] += ue[q];
-      }
-      const int pg = LT::SWZ ? (g ^ LT::key(slot)) : g;
-      reinterpret_cast<V*>(sm.t.R + (size_t)slot * D * D)[pg] = a;
-      reinterpret_cast<V*>(sm.t.Oc + (size_t)slot * D * D)[pg] = c;
-    }
-    for (int vi = tid; vi < n_real * D; vi += NT) {
-      const int slot = vi / D, i = vi % D;
-      const int64_t w = w0 + slot;
-      const T* r = rin + (size_t)w * rstride;
-      T v = r[RL::YS + i];
-      if (w != wlast) v += r[rstride + RL::DYA + i];
-      sm.t.y[vi] = v;
-    }
-    if (tid == 0) {                                       // the tile's own share for the row left of it
-      const T* r = rin + (size_t)w0 * rstride;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-#pragma unroll
-        for (int j = 0; j <= i; ++j) sm.xch[i * D + j] = r[RL::DRA + i * D + j];
-        sm.xch[D * D + i] = r[RL::DYA + i];
+        const int pg = LT::SWZ ? (g ^ LT::key(slot)) : g;
+        reinterpret_cast<V*>(sm.t.R + (size_t)slot * D * D)[pg] = ga[it];
+        reinterpret_cast<V*>(sm.t.Oc + (size_t)slot * D * D)[pg] = gc[it];
       }
     }
-    reduce_staged_tile_and_emit<T, D, NT>(sm.t, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah, fail);
-  } else {
+#pragma unroll
+    for (int it = 0; it < ITY; ++it) {
+      const int vi = tid + it * NT;
+      if (vi < n_real * D) sm.t.y[vi] = yv[it] + yu[it];
+    }
+#pragma unroll
+    for (int it = 0; it < OWN_IT; ++it) {
+      const int q = oi + 64 * it;
+      if (oi >= 0 && q < D * D + D) sm.xch[q] = own[it];  // xch[i*D+j] (lower triangle read), xch[D*D+i]
+    }
+    CGPS_FSTAMP(2);
+    reduce_staged_tile_and_emit<T, D, NT>(sm.t, n_real, sm.xch, FINAL ? (T*)nullptr : rout + (size_t)tile_index * RL::STRIDE, pl,
+                                          mah, fail);
+  }
+  }
+  if constexpr (!INL) {
+  if (!staged) {
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
   set_zero<T, D>(dya);
@@ -777,9 +979,11 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
     load_record_row<T, D>(rin, rstride, wb + j, n, wb + j != wlast, Rn, yn, On);
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
   }
-  reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, FINAL ? (T*)nullptr : rout, pl, mah,
-                                 fail);
+  reduce_tile_and_emit<T, D, NT>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch,
+                                 FINAL ? (T*)nullptr : rout + (size_t)tile_index * RL::STRIDE, pl, mah, fail);
   }
+  }
+  CGPS_FSTAMP(3);
   int64_t frow = (wb + rc) * rows_per_record;
   frow = (frow < N ? frow : N) - 1;
   if constexpr (!FINAL) {
@@ -793,7 +997,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
         if (p[2] != 0.0 && (fcode == 0 || (int)p[2] < fcode)) fcode = (int)p[2];
       }
     }
-    write_partial<NT>(mah, logp, fcode, partial_out, sm.red, sm.sfail);
+    write_partial<NT>(mah, logp, fcode, partial_out + PARTIAL_STRIDE * (size_t)tile_index, sm.red, sm.sfail);
   } else {
     if (tid == 0) {                        // the very last row of the whole system
       T A[D][D], x[D];
@@ -805,6 +1009,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
 #pragma unroll
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
     }
+    CGPS_FSTAMP(4);
     if (fail) atomicMin(sm.sfail, (int)(frow + 1));
     double logp = pl.value() + pre_logp;
     mah += pre_mah;
@@ -820,6 +1025,7 @@ __global__ __launch_bounds__(NT) void record_reduce_kernel(const T* __restrict__
       out2[1] = ok ? logp : poison;
       *info = ok ? 0 : f;
     }
+    CGPS_FSTAMP(5);
   }
 }
 
@@ -885,10 +1091,14 @@ void tile_set_attributes() {
   else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-    if constexpr (stage1_min_waves<T, D>() == 2)
+    if constexpr (stage1_min_waves<T, D>() == 2) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 8, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 4, Cfg::NT1>),
@@ -901,6 +1111,26 @@ void tile_set_attributes() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
   });
+}
+
+// slot of the arrival counter that belongs to this (device, workspace); -1 when all slots are taken
+// (the caller then runs the final stage as a second launch)
+inline int fold_slot_for(const void* ws) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> slots;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = slots.find({dev, ws});
+  if (it != slots.end()) return it->second;
+  if ((int)slots.size() >= FOLD_SLOTS) return -1;
+  const int s = (int)slots.size();
+  slots.emplace(std::make_pair(dev, ws), s);
+  return s;
+}
+inline bool fold_final_enabled() {          // CGPS_NO_FOLD=1: two launches as before (cross-check / A-B timing)
+  static const bool on = [] { const char* e = getenv("CGPS_NO_FOLD"); return !(e && e[0] == '1'); }();
+  return on;
 }
 
 // The fused pipeline.  Whole system: shard_record == nullptr, results in out2 / info.
@@ -932,13 +1162,13 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
                        lds1, st, Rs, Os, x, N, Oleft, recA, partial);
   else if (csel == 1)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 1, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial);
+                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   else if (csel == 4)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 4, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial);
+                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   else if (csel == 8)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 8, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial);
+                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   else {
     bool wide = false;
     if constexpr (stage1_min_waves<T, D>() == 2) {
@@ -946,13 +1176,24 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
       if (tiles <= STAGE1_SMALL_TILES) {
         wide = true;
         const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+        static_assert(Cfg::NG1 == Cfg::NTILE3 && 2 * Cfg::NT1 == Cfg::NT3, "fold_final reuses the stage-1 workgroup shape");
+        const int slot = (shard_record == nullptr && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled())
+                             ? fold_slot_for(ws) : -1;
+        if (slot >= 0) {
+          // the whole system in ONE launch: the workgroup that finishes last reduces the records
+          FoldArgs fa{slot, recB, out2, info};
+          hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
+                             dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+          if (ev_stop) (void)hipEventRecord(ev_stop, st);
+          return 0;
+        }
         hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
-                           dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial);
+                           dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
       }
     }
     if (!wide)
       hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                         Rs, Os, x, N, Oleft, recA, partial);
+                         Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   }
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;

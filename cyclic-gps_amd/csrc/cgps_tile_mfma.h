@@ -44,7 +44,14 @@ __device__ __forceinline__ double mfma444(double x, double y, double c) {  // X^
 // this level, s = its stride (see tile_cr).  Every lane of the workgroup must call this.
 // (Letting wave 0 run the last levels -- at most four eliminations each -- without barriers was
 // measured: no gain.)
-template <int NTHR>
+//
+// U = eliminations a 16-lane group carries through the arithmetic AT THE SAME TIME.  One chain is
+// a string of dependent fp64 instructions (a lone wave issues one per ~8-10 cycles); the
+// eliminations of a level are independent of each other, so U chains written side by side fill
+// each other's latency slots: a level with U times as many eliminations costs well under U times
+// one pass.  That is what lets the two widest levels of a 256-row tile (128 and 64 eliminations)
+// run in this form too instead of the role-split form of tile_cr.
+template <int NTHR, int U>
 __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K, int M, int s, PivotLog& pl, double& mah,
                                                    bool& fail) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,81 +62,111 @@ __device__ __forceinline__ void tile_cr_level_mfma(LdsTile<double, 4>& t, int K,
   const int g = (4 * r + c) >> 1, tb = c & 1;                   // this lane's element, straight and
   const int gT = (4 * c + r) >> 1, tT = r & 1;                  // transposed
   const bool c0 = (c == 0);
+  constexpr int PER = NTHR / 16;                                 // eliminations per chain set
 #pragma unroll 1
-  for (int k0 = 0; k0 < n_elim; k0 += NTHR / 16) {
+  for (int k0 = 0; k0 < n_elim; k0 += PER * U) {
     if (k0 + 4 * wave >= n_elim) continue;                       // (wave-uniform) nothing for this wave
-    const int k = k0 + 4 * wave + b;
-    const int e = (2 * k + 1) * s - 1;
-    const bool act = (2 * k < M) && (e != K);
-    const int o = (2 * k + 1 < M) ? e + s : K;
-    const bool pend_e = act && (s > 1) && (e + h < K);
-    const bool pend_o = act && (s > 1) && (o + h < K);
+    bool act[U];
+    int e[U], o[U], oRe[U], oRo[U], oOl[U];
+    double A[U], Ol[U], OrT[U], Ro[U], Y[U], yo[U];
     // ---- operands: one element per lane, branch-free (lanes without work read valid slots and
     // discard; y: every lane reads its row's entry, column 0 keeps it) --------------------------
-    const int oRe = mfma_elem_offset(act ? e : K, g, tb), oRo = mfma_elem_offset(act ? o : K, g, tb);
-    const int oOl = mfma_elem_offset(act ? e - s + 1 : 0, g, tb);
-    const int ye = (act ? e : K) * 4 + r, yoff = (act ? o : K) * 4 + r;
-    const int pe = pend_e ? e + h : K, po = pend_o ? o + h : K;
-    const double lA = t.R[oRe], lOl = t.Oc[oOl], lOr = t.Oc[mfma_elem_offset(act ? e + 1 : 0, gT, tT)];
-    const double lRo = t.R[oRo], lY = t.y[ye], lyo = t.y[yoff];
-    const double pA = t.R[mfma_elem_offset(pe, g, tb)], pY = t.y[pe * 4 + r];
-    const double pR = t.R[mfma_elem_offset(po, g, tb)], py = t.y[po * 4 + r];
-    double A = act ? (pend_e ? lA - pA : lA) : ident;
-    const double Ol = act ? lOl : 0.0, OrT = act ? lOr : 0.0;
-    double Ro = pend_o ? lRo - pR : lRo;
-    double Y = (act && c0) ? (pend_e ? lY - pY : lY) : 0.0;
-    double yo = pend_o ? lyo - py : lyo;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + PER * u + 4 * wave + b;
+      e[u] = (2 * k + 1) * s - 1;
+      act[u] = (2 * k < M) && (e[u] != K);
+      o[u] = (2 * k + 1 < M) ? e[u] + s : K;
+      const bool pend_e = act[u] && (s > 1) && (e[u] + h < K);
+      const bool pend_o = act[u] && (s > 1) && (o[u] + h < K);
+      oRe[u] = mfma_elem_offset(act[u] ? e[u] : K, g, tb);
+      oRo[u] = mfma_elem_offset(act[u] ? o[u] : K, g, tb);
+      oOl[u] = mfma_elem_offset(act[u] ? e[u] - s + 1 : 0, g, tb);
+      const int ye = (act[u] ? e[u] : K) * 4 + r, yoff = (act[u] ? o[u] : K) * 4 + r;
+      const int pe = pend_e ? e[u] + h : K, po = pend_o ? o[u] + h : K;
+      const double lA = t.R[oRe[u]], lOl = t.Oc[oOl[u]], lOr = t.Oc[mfma_elem_offset(act[u] ? e[u] + 1 : 0, gT, tT)];
+      const double lRo = t.R[oRo[u]], lY = t.y[ye], lyo = t.y[yoff];
+      const double pA = t.R[mfma_elem_offset(pe, g, tb)], pY = t.y[pe * 4 + r];
+      const double pR = t.R[mfma_elem_offset(po, g, tb)], py = t.y[po * 4 + r];
+      A[u] = act[u] ? (pend_e ? lA - pA : lA) : ident;
+      Ol[u] = act[u] ? lOl : 0.0;
+      OrT[u] = act[u] ? lOr : 0.0;
+      Ro[u] = pend_o ? lRo - pR : lRo;
+      Y[u] = (act[u] && c0) ? (pend_e ? lY - pY : lY) : 0.0;
+      yo[u] = pend_o ? lyo - py : lyo;
+    }
     // (every writer of a row or of a parked update stores the full symmetric block, so A and Ro
     // are symmetric as loaded)
     // ---- Li = L^-1 of A = L L^T, right-looking over the 16 lanes ------------------------------
-    double B = ident, piv = 1.0;
-    bool f = false;
+    double B[U], piv[U];
+    bool f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { B[u] = ident; piv[u] = 1.0; f[u] = false; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const double sel = (r == kk) ? 1.0 : 0.0;
-      const double rowA = mfma444(sel, A, 0.0);                  // A[kk][c] in every row
-      const double rowB = mfma444(sel, B, 0.0);                  // B[kk][c]
-      double p, col;
-      if (kk == 0) { p = quad_bcast_f64<0>(rowA); col = quad_bcast_f64<0>(A); }
-      else if (kk == 1) { p = quad_bcast_f64<1>(rowA); col = quad_bcast_f64<1>(A); }
-      else if (kk == 2) { p = quad_bcast_f64<2>(rowA); col = quad_bcast_f64<2>(A); }
-      else { p = quad_bcast_f64<3>(rowA); col = quad_bcast_f64<3>(A); }
-      f = f || !(p > 0.0);
-      piv *= p;
-      const double rs = rsqrt_fast(p);
-      const double lik = col * rs;                               // L[r][kk]
-      const double ra = rowA * rs, rb = rowB * rs;               // L[c][kk];  row kk of B / L[kk][kk]
-      if (r > kk) {
-        A = __builtin_fma(-lik, ra, A);
-        B = __builtin_fma(-lik, rb, B);
-      } else if (r == kk) {
-        B = rb;
+      double rowA[U], rowB[U], p[U], col[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        rowA[u] = mfma444(sel, A[u], 0.0);                       // A[kk][c] in every row
+        rowB[u] = mfma444(sel, B[u], 0.0);                       // B[kk][c]
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (kk == 0) { p[u] = quad_bcast_f64<0>(rowA[u]); col[u] = quad_bcast_f64<0>(A[u]); }
+        else if (kk == 1) { p[u] = quad_bcast_f64<1>(rowA[u]); col[u] = quad_bcast_f64<1>(A[u]); }
+        else if (kk == 2) { p[u] = quad_bcast_f64<2>(rowA[u]); col[u] = quad_bcast_f64<2>(A[u]); }
+        else { p[u] = quad_bcast_f64<3>(rowA[u]); col[u] = quad_bcast_f64<3>(A[u]); }
+        f[u] = f[u] || !(p[u] > 0.0);
+        piv[u] *= p[u];
+      }
+      double rs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) rs[u] = rsqrt_fast(p[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double lik = col[u] * rs[u];                       // L[r][kk]
+        const double ra = rowA[u] * rs[u], rb = rowB[u] * rs[u]; // L[c][kk];  row kk of B / L[kk][kk]
+        if (r > kk) {
+          A[u] = __builtin_fma(-lik, ra, A[u]);
+          B[u] = __builtin_fma(-lik, rb, B[u]);
+        } else if (r == kk) {
+          B[u] = rb;
+        }
       }
     }
     // ---- the products ----------------------------------------------------------------------------
-    const double U = mfma444(B, ident, 0.0);                      // Li^T
-    const double Gt = mfma444(U, Ol, 0.0);                        // Li Ol   = G^T
-    const double Ft = mfma444(U, OrT, 0.0);                       // Li Or^T = F^T
-    const double X = mfma444(U, Y, 0.0);                          // column 0: x = Li y
-    const double GGt = mfma444(Gt, Gt, 0.0);                      // G G^T   (owed to the left neighbour: parked)
-    const double Gx = mfma444(Gt, X, 0.0);                        // column 0: G x
-    const double FFt = mfma444(Ft, Ft, 0.0);
-    const double Fx = mfma444(Ft, X, 0.0);
-    const double FGt = mfma444(Ft, Gt, 0.0);                      // F G^T
-    // ---- results (disjoint slots per elimination: no barrier between reads and writes) -----------
-    if (act) {
-      t.R[oRe] = GGt;
-      t.R[oRo] = Ro - FFt;
-      t.Oc[oOl] = -FGt;
+    double Um[U], Gt[U], Ft[U], X[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) Um[u] = mfma444(B[u], ident, 0.0);        // Li^T
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      Gt[u] = mfma444(Um[u], Ol[u], 0.0);                        // Li Ol   = G^T
+      Ft[u] = mfma444(Um[u], OrT[u], 0.0);                       // Li Or^T = F^T
+      X[u] = mfma444(Um[u], Y[u], 0.0);                          // column 0: x = Li y
     }
-    if (act && c0) {
-      t.y[e * 4 + r] = Gx;
-      t.y[o * 4 + r] = yo - Fx;
-      mah += X * X;
-    }
-    if (act && c0 && r == 0) {
-      pl.mul(piv);
-      fail = fail || f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double GGt = mfma444(Gt[u], Gt[u], 0.0);             // G G^T   (owed to the left neighbour: parked)
+      const double Gx = mfma444(Gt[u], X[u], 0.0);               // column 0: G x
+      const double FFt = mfma444(Ft[u], Ft[u], 0.0);
+      const double Fx = mfma444(Ft[u], X[u], 0.0);
+      const double FGt = mfma444(Ft[u], Gt[u], 0.0);             // F G^T
+      // ---- results (disjoint slots per elimination: no barrier between reads and writes) ---------
+      if (act[u]) {
+        t.R[oRe[u]] = GGt;
+        t.R[oRo[u]] = Ro[u] - FFt;
+        t.Oc[oOl[u]] = -FGt;
+      }
+      if (act[u] && c0) {
+        t.y[e[u] * 4 + r] = Gx;
+        t.y[o[u] * 4 + r] = yo[u] - Fx;
+        mah += X[u] * X[u];
+      }
+      if (act[u] && c0 && r == 0) {
+        pl.mul(piv[u]);
+        fail = fail || f[u];
+      }
     }
   }
   __syncthreads();

@@ -281,5 +281,5 @@ __global__ __launch_bounds__(NT, 2) void chunk_reduce_ml_kernel(const T* __restr
     store_vec<T, D>(r + RL::DYA, dyl);
   }
   int64_t frow = r0 < N ? r0 : N - 1;
-  write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial, sm.red, sm.sfail);
+  write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
 }

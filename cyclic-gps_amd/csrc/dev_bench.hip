@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define CGPS_FIN_STAMPS 1
 #include "cgps_tile.h"
 
 using namespace cgps;
@@ -151,6 +152,82 @@ static void run_mfma_probe() {
   }
 }
 
+
+// ---- tile_cr alone: one 256-slot tile per workgroup, per-policy wall time of the in-LDS reduction ----
+// (wall_clock64: 100 MHz).  n_real rows are regenerated before every repetition; the time of the
+// reduction itself is stamped by thread 0 between two barriers.
+template <int NTHR, int MW>
+__global__ __launch_bounds__(NTHR) void tilecr_bench_kernel(int n_real, int reps, long long* ticks, double* sums) {
+  using T = double;
+  constexpr int D = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  StageSmem<T, D, 256, NTHR> sm(smem);
+  const int tid = threadIdx.x;
+  long long acc = 0;
+  double mah = 0.0;
+  PivotLog pl;
+  bool fail = false;
+  for (int rep = 0; rep < reps; ++rep) {
+    if (tid < n_real) {
+      unsigned h = (unsigned)((tid + 977 * blockIdx.x) * 2654435761u) ^ 0x9e3779b9u;
+      auto rnd = [&]() { h = h * 1664525u + 1013904223u; return (T)((h >> 8) & 0xffff) / (T)65536 - (T)0.5; };
+      T R[D][D], O[D][D], y[D];
+      for (int a = 0; a < D; ++a) {
+        for (int b = 0; b <= a; ++b) { T v = (a == b) ? (T)2.5 + (T)0.2 * rnd() : (T)0.1 * rnd(); R[a][b] = v; R[b][a] = v; }
+        for (int b = 0; b < D; ++b) O[a][b] = (T)0.3 * rnd();
+        y[a] = rnd();
+      }
+      LdsTile<T, D>::store_blk(sm.t.R, tid, R);
+      LdsTile<T, D>::store_blk(sm.t.Oc, tid, O);
+      store_vec<T, D>(sm.t.y + tid * D, y);
+    }
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    tile_cr<T, D, NTHR, MW>(sm.t, n_real, pl, mah, fail);
+    const long long t1 = wall_clock64();
+    __syncthreads();
+    acc += t1 - t0;
+  }
+  double logp = pl.value();
+  block_sum2<NTHR>(mah, logp, sm.red);
+  if (tid == 0) {
+    ticks[blockIdx.x] = acc;
+    sums[2 * blockIdx.x] = mah;
+    sums[2 * blockIdx.x + 1] = logp;
+  }
+}
+
+template <int NTHR, int MW>
+void run_tilecr(int grid, hipStream_t st) {
+  const size_t lds = stage_lds_bytes<double, 4>(256, NTHR);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tilecr_bench_kernel<NTHR, MW>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  long long* ticks;
+  double* sums;
+  CK(hipMalloc(&ticks, grid * sizeof(long long)));
+  CK(hipMalloc(&sums, 2 * grid * sizeof(double)));
+  const int reps = 50;
+  printf("tile_cr NTHR=%d MW=%d grid=%d :", NTHR, MW, grid);
+  double prev = 0;
+  for (int n_real : {2, 4, 8, 16, 32, 64, 128, 256}) {
+    hipLaunchKernelGGL((tilecr_bench_kernel<NTHR, MW>), dim3(grid), dim3(NTHR), lds, st, n_real, reps, ticks, sums);
+    CK(hipStreamSynchronize(st));
+    std::vector<long long> h(grid);
+    std::vector<double> hs(2 * grid);
+    CK(hipMemcpy(h.data(), ticks, grid * sizeof(long long), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hs.data(), sums, 2 * grid * sizeof(double), hipMemcpyDeviceToHost));
+    double avg = 0;
+    for (auto v : h) avg += (double)v;
+    avg = avg / grid / reps * 10.0;   // ns
+    printf("  n=%d: %.0f ns (+%.0f)", n_real, avg, avg - prev);
+    if (n_real == 256) printf("  [check %.10g %.10g]", hs[0], hs[1]);
+    prev = avg;
+  }
+  printf("\n");
+  CK(hipFree(ticks));
+  CK(hipFree(sums));
+}
+
 template <typename F>
 float time_ms(F&& launch, int reps, hipStream_t st) {
   hipEvent_t a, b;
@@ -182,6 +259,59 @@ int main(int argc, char** argv) {
   constexpr int D = 4;
   const int lg = argc > 1 ? atoi(argv[1]) : 20;
   const int64_t N = (int64_t)1 << lg;
+  if (argc > 2 && atoi(argv[2]) == 2) {           // dev_bench 20 2: stamps inside the final reduction of the real pipeline
+    hipStream_t s2;
+    CK(hipStreamCreate(&s2));
+    T *R2, *O2, *y2;
+    CK(hipMalloc(&R2, N * D * D * sizeof(T)));
+    CK(hipMalloc(&O2, N * D * D * sizeof(T)));
+    CK(hipMalloc(&y2, N * D * sizeof(T)));
+    hipLaunchKernelGGL((gen_kernel<T, D>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s2, R2, O2, y2, N);
+    const size_t wsb = tile_ws_bytes(N, D, sizeof(T));
+    char* ws;
+    double* out2;
+    int* info;
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMalloc(&out2, 16));
+    CK(hipMalloc(&info, 4));
+    for (int mode = 0; mode < 2; ++mode) {
+      setenv("CGPS_NO_FOLD", mode == 0 ? "1" : "0", 1);
+      for (int it = 0; it < 30; ++it) {
+        hipEvent_t ea, eb;
+        CK(hipEventCreate(&ea));
+        CK(hipEventCreate(&eb));
+        CK(hipEventRecord(ea, s2));
+        int rc = run_tile_mahal_logdet<T, D>(R2, O2, y2, N, ws, wsb, out2, info, s2);
+        CK(hipEventRecord(eb, s2));
+        CK(hipStreamSynchronize(s2));
+        float ms;
+        CK(hipEventElapsedTime(&ms, ea, eb));
+        long long st[16];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fin_stamps), sizeof(st)));
+        double o[2];
+        CK(hipMemcpy(o, out2, 16, hipMemcpyDeviceToHost));
+        if (it >= 27)
+          printf("mode %s rc %d: op %.1f us | final: loads %.2f  lds-stores %.2f  reduce %.2f  last-row %.2f  sums+write %.2f  total %.2f us  [%.10g %.10g]\n",
+                 mode == 0 ? "two launches" : "folded", rc, ms * 1e3, (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01,
+                 (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01, (st[5] - st[0]) * 0.01, o[0], o[1]);
+      }
+      break;   // fold_final_enabled() latches the environment at first use: one mode per process
+    }
+    return 0;
+  }
+  if (argc > 2 && atoi(argv[2]) == 1) {           // dev_bench 20 1: only the in-LDS reduction timings
+    hipStream_t s2;
+    CK(hipStreamCreate(&s2));
+    for (int grid : {1, 256}) {
+      run_tilecr<256, 1>(grid, s2);
+      run_tilecr<256, 2>(grid, s2);
+      run_tilecr<256, 4>(grid, s2);
+      run_tilecr<512, 1>(grid, s2);
+      run_tilecr<512, 2>(grid, s2);
+      run_tilecr<512, 4>(grid, s2);
+    }
+    return 0;
+  }
   hipStream_t st;
   CK(hipStreamCreate(&st));
   T *R, *O, *y;

@@ -194,3 +194,37 @@ def test_full_size_closed_form(N, d, dtype, rtol):
     # the solve is linear: J^-1 (2b) == 2 J^-1 b
     x2 = cr.solve(dec, 2 * b)
     assert float((x2 - 2 * x).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-3)
+
+
+def test_folded_final_stage_never_reads_stale_records():
+    """At 2^19 < N <= 2^20 rows (d = 4, fp64) the whole reduction is ONE launch: stage-1 workgroups hand
+    their records to the workgroup that arrives last, inside the launch (csrc/cgps_tile.h, fold_final).
+    A stale read there would go unnoticed when the same system is solved again and again (the stale
+    record equals the fresh one), so alternate between DIFFERENT systems that share one workspace --
+    caches warm with the other system's records -- and check every single result, bit for bit,
+    against the first result of that system and against the one-launch-per-level form."""
+    n, d = 2 ** 20, 4
+    systems = []
+    for seed in (11, 12, 13):
+        Rs, Os, b, x_true, logdet = _util.conditioned_system(n - 4096 * (seed - 11), d, seed=seed, device="cuda")
+        ref = cr._mahal_and_det(Rs, Os, b, levelwise=True)
+        systems.append((Rs, Os, b, float(ref[0]), float(ref[1]), logdet))
+    first = [None] * len(systems)
+    cr.CHECK_POSITIVE_DEFINITE = False
+    try:
+        outs = []
+        for it in range(150):
+            k = (it * 7 + it // 5) % len(systems)
+            Rs, Os, b, m_ref, ld_ref, logdet = systems[k]
+            outs.append((k, cr.mahal_and_det(Rs, Os, b)))
+        torch.cuda.synchronize()
+    finally:
+        cr.CHECK_POSITIVE_DEFINITE = True
+    for k, (m, ld) in outs:
+        Rs, Os, b, m_ref, ld_ref, logdet = systems[k]
+        m, ld = float(m), float(ld)
+        if first[k] is None:
+            first[k] = (m, ld)
+            assert abs(ld - logdet) <= 1e-10 * abs(logdet)
+            assert abs(ld - ld_ref) <= 1e-11 * abs(ld_ref) and abs(m - m_ref) <= 1e-9 * abs(m_ref)
+        assert (m, ld) == first[k], (k, m, ld, first[k])
