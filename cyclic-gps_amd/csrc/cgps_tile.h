@@ -136,7 +136,8 @@ struct PivotLog {
     prod *= p;
     if (!(prod > 1e-150 && prod < 1e150)) { logsum += log(prod); prod = 1.0; }
   }
-  __device__ __forceinline__ double value() const { return logsum + log(prod); }
+  // (most lanes of the narrow record stages never saw a pivot: no log for them)
+  __device__ __forceinline__ double value() const { return prod == 1.0 ? logsum : logsum + log(prod); }
 };
 
 template <typename T, int D>
@@ -440,7 +441,10 @@ __device__ __forceinline__ typename Vec16<T>::type load16_coh(const T* p) {
 // one slot (fold_slot_for): two launches may be in flight at the same time only with different
 // workspaces (include/cgps.h), hence with different counters.
 constexpr int FOLD_SLOTS = 1024;
-constexpr int FOLD_GROUP = 16;              // stage-1 records per group (fold_final, below)
+#ifndef CGPS_FOLD_GROUP
+#define CGPS_FOLD_GROUP 16
+#endif
+constexpr int FOLD_GROUP = CGPS_FOLD_GROUP; // stage-1 records per group (fold_final, below)
 constexpr int FOLD_MAX_GROUPS = 16;         // <= 256 stage-1 workgroups
 // [slot][0]: arrivals of the group leaders; [slot][1 + g]: arrivals of group g's workgroups
 static __device__ unsigned int g_fold_counter[FOLD_SLOTS][1 + FOLD_MAX_GROUPS];
@@ -624,6 +628,20 @@ struct StageSmem {
   }
 };
 
+// dev-only wall-clock stamps of the final reduction (dev_bench.hip defines CGPS_FIN_STAMPS; no stamp
+// executes in the library build)
+#ifdef CGPS_FIN_STAMPS
+static __device__ long long g_fin_stamps[16];
+static __device__ long long g_k_stamps[512][8];
+static __device__ int g_k_xcc[512];
+#define CGPS_KSTAMP(k) do { if (threadIdx.x == 0) { g_k_stamps[blockIdx.x][k] = wall_clock64(); \
+  if ((k) == 0) g_k_xcc[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11))); } } while (0)
+#define CGPS_FSTAMP(k) do { if (FINAL && threadIdx.x == 0) g_fin_stamps[k] = wall_clock64(); } while (0)
+#else
+#define CGPS_FSTAMP(k) do { } while (0)
+#define CGPS_KSTAMP(k) do { } while (0)
+#endif
+
 // ---- stage 1 -----------------------------------------------------------------------------
 // (two workgroups per CU = two waves per SIMD: the streaming phase needs the second wave to
 // cover HBM latency when the grid is larger than the chip, so registers are capped at 256)
@@ -663,6 +681,7 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   StageSmem<T, D, NT, NW> sm(smem);
   const int tid = threadIdx.x;
+  CGPS_KSTAMP(0);
   if (tid == 0) *sm.sfail = 0x7fffffff;
   const int64_t lane0 = (int64_t)blockIdx.x * NT;
   const int64_t r0 = tid < NT ? (lane0 + tid) * C : N;          // threads past the lanes hold no rows
@@ -723,12 +742,15 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   // (the tile is written only after the workgroup-wide barrier inside reduce_tile_and_emit: no lane
   // is still reading its y line then)
 
+  CGPS_KSTAMP(1);
   int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
   const int n_real = nreal64 > NT ? NT : (int)nreal64;
   reduce_tile_and_emit<T, D, NW>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec + (size_t)blockIdx.x * RecordLayout<T, D>::STRIDE,
                                  pl, mah, fail);
+  CGPS_KSTAMP(2);
   int64_t frow = r0 < N ? r0 : N - 1;
   write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
+  CGPS_KSTAMP(3);
   if constexpr (FOLD) {
     static_assert(NW == 2 * NT, "fold_final runs the record stages with the wide workgroup");
     // Two levels inside the launch.  The workgroups of a GROUP of FOLD_GROUP consecutive tiles
@@ -766,29 +788,26 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
     };
     T* grec = reinterpret_cast<T*>(fold.group_records);
     double* gpartial = partial + PARTIAL_STRIDE * (size_t)gridDim.x;       // the groups' partial results
-    if (arrive(&g_fold_counter[fold.slot][1 + grp], gsize)) {
+    const bool lead = arrive(&g_fold_counter[fold.slot][1 + grp], gsize);
+    CGPS_KSTAMP(4);
+    if (lead) {
       record_reduce_body<T, D, FOLD_GROUP, NW, false, COH>(smem, grp, rec, (int64_t)gridDim.x, 1, grec, gpartial,
                                                            (const double*)nullptr, (int64_t)0, (double*)nullptr,
                                                            (int*)nullptr, (int64_t)C * NT, N, (int64_t)RL::STRIDE,
                                                            (int64_t)PARTIAL_STRIDE);
-      if (arrive(&g_fold_counter[fold.slot][0], ngrp)) {
+      CGPS_KSTAMP(5);
+      const bool fin = arrive(&g_fold_counter[fold.slot][0], ngrp);
+      CGPS_KSTAMP(6);
+      if (fin) {
         record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr, (double*)nullptr,
                                                                  partial, (int64_t)gridDim.x + ngrp, fold.out2, fold.info,
                                                                  (int64_t)C * NT * FOLD_GROUP, N, (int64_t)RL::STRIDE,
                                                                  (int64_t)PARTIAL_STRIDE);
+        CGPS_KSTAMP(7);
       }
     }
   }
 }
-
-// dev-only wall-clock stamps of the final reduction (dev_bench.hip defines CGPS_FIN_STAMPS; no stamp
-// executes in the library build)
-#ifdef CGPS_FIN_STAMPS
-static __device__ long long g_fin_stamps[16];
-#define CGPS_FSTAMP(k) do { if (FINAL && threadIdx.x == 0) g_fin_stamps[k] = wall_clock64(); } while (0)
-#else
-#define CGPS_FSTAMP(k) do { } while (0)
-#endif
 
 // ---- stage 3 -----------------------------------------------------------------------------
 // Records in -> records out (FINAL = false), or -> out2 = {mahal, logdet} and info (FINAL =

@@ -274,7 +274,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&ws, wsb));
     CK(hipMalloc(&out2, 16));
     CK(hipMalloc(&info, 4));
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 2; ++mode) {     // dev_bench 20 2 <0: two launches | 1: folded>
       setenv("CGPS_NO_FOLD", mode == 0 ? "1" : "0", 1);
       for (int it = 0; it < 30; ++it) {
         hipEvent_t ea, eb;
@@ -290,6 +290,39 @@ int main(int argc, char** argv) {
         CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fin_stamps), sizeof(st)));
         double o[2];
         CK(hipMemcpy(o, out2, 16, hipMemcpyDeviceToHost));
+        if (it >= 28) {
+          static long long ks[512][8];
+          CK(hipMemcpyFromSymbol(ks, HIP_SYMBOL(g_k_stamps), sizeof(ks)));
+          long long t0 = ks[0][0];
+          for (int b = 0; b < 256; ++b) t0 = ks[b][0] < t0 ? ks[b][0] : t0;
+          static int xcc[512];
+          CK(hipMemcpyFromSymbol(xcc, HIP_SYMBOL(g_k_xcc), sizeof(xcc)));
+          double sx[8] = {0}, mx[8] = {0};
+          int cx[8] = {0};
+          for (int b = 0; b < 256; ++b) {
+            const int x = xcc[b] & 7;
+            const double d = (ks[b][1] - t0) * 0.01;
+            sx[x] += d; cx[x]++; mx[x] = d > mx[x] ? d : mx[x];
+          }
+          printf("   stream end per XCD (avg/max us):");
+          for (int x = 0; x < 8; ++x) printf(" [%d: n=%d %.1f/%.1f]", x, cx[x], cx[x] ? sx[x] / cx[x] : 0.0, mx[x]);
+          printf("\n   stream end by block index (us):");
+          for (int b = 0; b < 256; b += 17) printf(" b%d:%.1f", b, (ks[b][1] - t0) * 0.01);
+          printf("\n");
+          const char* names[8] = {"start", "streamed", "tile reduced+emitted", "partial written", "arrived(group)",
+                                  "group reduced", "arrived(top)", "final done"};
+          for (int k = 0; k < 8; ++k) {
+            long long lo = 1LL << 62, hi = 0;
+            int cnt = 0;
+            for (int b = 0; b < 256; ++b) {
+              if (ks[b][k] < t0) continue;            // not reached in this launch
+              lo = ks[b][k] < lo ? ks[b][k] : lo;
+              hi = ks[b][k] > hi ? ks[b][k] : hi;
+              ++cnt;
+            }
+            if (cnt) printf("   %-22s first %.2f us  last %.2f us  (%d workgroups)\n", names[k], (lo - t0) * 0.01, (hi - t0) * 0.01, cnt);
+          }
+        }
         if (it >= 27)
           printf("mode %s rc %d: op %.1f us | final: loads %.2f  lds-stores %.2f  reduce %.2f  last-row %.2f  sums+write %.2f  total %.2f us  [%.10g %.10g]\n",
                  mode == 0 ? "two launches" : "folded", rc, ms * 1e3, (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01,

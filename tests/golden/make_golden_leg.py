@@ -20,8 +20,16 @@ import _refload  # noqa: E402
 warnings.filterwarnings("ignore")
 
 
-def record(model, ts, xs, naive=None):
+def record(model, ts, xs, naive=None, target_ts=None):
     model.register_model_matrices_from_params()
+    pred = {}
+    if target_ts is not None:
+        # prediction glue (models.py:394-546, model_utils.py:64-107): forecast / interpolate / exact hits
+        with torch.no_grad():
+            pp_mean, pp_cov = model.predictive_posterior(ts, xs, target_ts)
+            p_mean, p_cov = model.make_predictions(ts, xs, target_ts)
+        pred = dict(target_ts=target_ts.numpy(), pp_mean=pp_mean.numpy(), pp_cov=pp_cov.numpy(),
+                    pred_mean=p_mean.numpy(), pred_cov=p_cov.numpy())
     with torch.no_grad():
         Sig_Rs, Sig_Os = model.compute_PEG_precision(ts)
         K_Rs, K_Os = model.compute_posterior_precision(ts)
@@ -34,6 +42,7 @@ def record(model, ts, xs, naive=None):
                post_cov_Rs=cov["Rs"].numpy(), post_cov_Os=cov["Os"].numpy())
     if naive is not None:
         out["naive_ll"] = float(naive)
+    out.update(pred)
     return out
 
 
@@ -65,12 +74,16 @@ def main():
     src = open(spec.origin).read().replace("from . import cyclic_reduction as cr", "cr = None")
     ns = {}
     exec(compile(src, spec.origin, "exec"), ns)
-    _, _, train_ts, train_xs = ns["co2_workload"]()
+    all_ts, _, train_ts, train_xs = ns["co2_workload"]()
+    # every month of the series (training months = exact hits, the masked gap = interpolation, the held-out
+    # tail = forecast) plus a few times before the first observation and in between months
+    co2_targets = torch.sort(torch.cat([all_ts, torch.tensor([-30.0, -7.5, -0.25], dtype=all_ts.dtype),
+                                        all_ts[100:110] + 0.37, all_ts[-1:] + 17.0]))[0]
 
     torch.manual_seed(20240611)
     m = models.LEGFamily(rank=5, obs_dim=1, train=False, data_type=torch.float64)
     m.double()
-    rec = record(m, train_ts, train_xs)
+    rec = record(m, train_ts, train_xs, target_ts=co2_targets)
     rec.update(record_grads(models, train_ts, train_xs, 20240611, 5, 1))
     np.savez_compressed(os.path.join(HERE, "leg_co2like.npz"), **rec)
 
@@ -90,7 +103,9 @@ def main():
         m.double()
         naive = compute_log_marginal_likelihood(N=m.N, R=m.R, B=m.B.detach(), Lambda=m.calc_Lambda_Lambda_T(m.Lambda),
                                                 ts=ts, xs=xs)
-        np.savez_compressed(os.path.join(HERE, "leg_small_%s.npz" % spacing), **record(m, ts, xs, naive))
+        targets = torch.sort(torch.cat([ts[:1] - 2.0, ts[:1], 0.5 * (ts[3:9] + ts[4:10]), ts[15:17], ts[-1:], ts[-1:] + 0.75,
+                                        ts[-1:] + 6.0]))[0]
+        np.savez_compressed(os.path.join(HERE, "leg_small_%s.npz" % spacing), **record(m, ts, xs, naive, target_ts=targets))
     print("wrote LEG golden files")
 
 

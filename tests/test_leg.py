@@ -126,3 +126,56 @@ def test_hip_operand_assembly_reports_a_zero_gap():
     ts[5] = ts[4]
     with pytest.raises(leg.cr.NotPSDError):
         leg.peg_precision(ts, m.G)
+
+
+# ---- prediction glue (cyclic_gps/predict.py; reference models.py:394-546, model_utils.py:64-107) ----------
+def _check_predictions(name, device):
+    from cyclic_gps import predict
+    g, m, ts, xs = _load(name, device=device)
+    target_ts = torch.from_numpy(g["target_ts"]).to(device)
+    mean = torch.from_numpy(g["post_mean"]).to(device)
+    cov = {"Rs": torch.from_numpy(g["post_cov_Rs"]).to(device), "Os": torch.from_numpy(g["post_cov_Os"]).to(device)}
+    return predict, g, m, ts, xs, target_ts, mean, cov
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_intercast_matches_reference_given_its_insample_posterior(name):
+    """The batched glue alone (CPU tensors, no kernels): fed the reference's own in-sample posterior it
+    reproduces the reference's predictive posterior at every target (backward / forward forecasts,
+    exact hits of the first, last and interior observations, interpolation inside the masked gap)."""
+    predict, g, m, ts, xs, target_ts, mean, cov = _check_predictions(name, "cpu")
+    pm, pv = predict.intercast(m, mean, cov, ts, target_ts)
+    np.testing.assert_allclose(pm.numpy(), g["pp_mean"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pv.numpy(), g["pp_cov"], rtol=1e-6, atol=1e-8)
+    # the un-batched building blocks, one target at a time like the reference calls them
+    k = int(np.searchsorted(g["ts"], g["target_ts"][3]))
+    if 0 < k < ts.shape[0]:
+        t = target_ts[3]
+        e1, e2 = predict.compute_eG(m.G, (t - ts[k - 1])[None])[0], predict.compute_eG(m.G, (ts[k] - t)[None])[0]
+        m1, v1 = predict.interpolate(e1, e2, mean[k - 1], cov["Rs"][k - 1], cov["Os"][k - 1], mean[k], cov["Rs"][k])
+        np.testing.assert_allclose(m1.numpy(), g["pp_mean"][3], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(v1.numpy(), g["pp_cov"][3], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_make_predictions_on_gpu(name):
+    """End to end on the device: HIP in-sample posterior + batched glue against the reference's
+    make_predictions (north_star tolerance 1e-4; fp64 agrees far tighter)."""
+    predict, g, m, ts, xs, target_ts, _, _ = _check_predictions(name, "cuda")
+    pm, pv = predict.make_predictions(m, ts, xs, target_ts)
+    assert pm.device.type == "cuda"
+    np.testing.assert_allclose(pm.cpu().numpy(), g["pred_mean"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(pv.cpu().numpy(), g["pred_cov"], rtol=1e-6, atol=1e-7)
+    lm, lv = predict.predictive_posterior(m, ts, xs, target_ts)
+    np.testing.assert_allclose(lm.cpu().numpy(), g["pp_mean"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(lv.cpu().numpy(), g["pp_cov"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_make_predictions_fp32_within_1e4():
+    predict, g, m, ts, xs, target_ts, _, _ = _check_predictions("leg_co2like", "cuda")
+    m32 = leg.LEGMatrices(*(t.float() for t in (m.N, m.R, m.B, m.Lambda)))
+    pm, _ = predict.make_predictions(m32, ts.float(), xs.float(), target_ts.float())
+    err = np.abs(pm.cpu().double().numpy() - g["pred_mean"]).max()
+    assert err <= 1e-4 * max(1.0, np.abs(g["pred_mean"]).max()), err
