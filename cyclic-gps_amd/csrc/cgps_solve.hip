@@ -4,6 +4,7 @@
 #include "cgps_host.h"
 #include "cgps_tile.h"
 #include "cgps_solve_tile.h"
+#include "cgps_solve_tile_m.h"
 
 using namespace cgps_host;
 
@@ -16,7 +17,7 @@ struct SolvePasses {
   int64_t rows[8];
 };
 
-void make_passes(const Layout& L, SolvePasses& P, int wide_lp) {
+void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts = cgps::SOLVE_TS, int lp = cgps::SOLVE_LP) {
   P.np = 0;
   int lvl = 0;
   while (lvl < L.nlevels) {
@@ -24,8 +25,7 @@ void make_passes(const Layout& L, SolvePasses& P, int wide_lp) {
     const int remaining = L.nlevels - lvl;
     // many tiles: a few levels per pass (every lane busy, few barrier-separated latency
     // exposures, the factor still read once); few tiles: all ten levels of a tile
-    const int nl = (rows <= cgps::SOLVE_TS) ? remaining
-                   : (rows >= cgps::SOLVE_WIDE_ROWS ? wide_lp : cgps::SOLVE_LP);   // <= SOLVE_LP + 1
+    const int nl = (rows <= ts) ? remaining : (rows >= cgps::SOLVE_WIDE_ROWS ? wide_lp : lp);   // <= lp + 1
     cgps::PassLevels& pl = P.lv[P.np];
     pl.nlev = nl;
     pl.endD = L.offD[lvl + nl];
@@ -191,41 +191,194 @@ int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, co
   }
   return check_launch("backsolve");
 }
+
+// ---- several right-hand sides per sweep: cgps_solve_tile_m.h ----------------------------------------
+// Workspace of one panel sweep (MC columns): partial sums | two ping-pong buffers of [N/2+1][D][MC].
+struct PanelWs {
+  size_t partial_bytes, buf_bytes, total;
+};
+inline PanelWs panel_ws(int64_t N, int d, size_t s, int mc, int chunks) {
+  PanelWs w{};
+  // grids of all passes of all chunks: < 1.2 N / 128 tiles per chunk (the smallest tile has 128 rows)
+  const int64_t tiles = (N / 128 + 64) * 2;
+  w.partial_bytes = align_up((size_t)(tiles * chunks + 2) * 16);
+  w.buf_bytes = align_up((size_t)(N / 2 + 2) * d * mc * s);
+  w.total = w.partial_bytes + 2 * w.buf_bytes;
+  return w;
+}
+inline int panel_width(int nrhs) { return nrhs <= 2 ? 2 : (nrhs <= 4 ? 4 : 8); }
+
+template <typename T, int D, int MC>
+void solve_m_attributes() {
+  static PerDevice<int> done;
+  done.get([](int) {
+    const int lds = (int)cgps::solve_m_lds_bytes<T, D, MC>();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_tile_m_kernel<T, D, MC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_m_kernel<T, D, MC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return 1;
+  });
+}
+
+// forward sweep of w <= MC columns: y [N][D][ld_y] -> xcrr [N][D][ld_x]; partial sums appended at *pb
+template <typename T, int D, int MC>
+int run_halfsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, int ld_y, int w, T* xcrr, int ld_x,
+                        double* partial, int64_t* pb, T* buf0, T* buf1, hipStream_t st) {
+  constexpr int TSL = cgps::solve_m_tile_log2<MC>(), TS = 1 << TSL, NT = TS / 2, PW = D * MC;
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL);
+  solve_m_attributes<T, D, MC>();
+  T* bufs[2] = {buf0, buf1};
+  const size_t lds = cgps::solve_m_lds_bytes<T, D, MC>();
+  const T* y = y0;
+  int ld = ld_y;
+  const T* owed_in = nullptr;
+  int64_t n_owed = 0;
+  int spt_in = 1;
+  for (int p = 0; p < P.np; ++p) {
+    const int64_t n = P.rows[p], g = (n + TS - 1) / TS;
+    const bool more = (p + 1 < P.np);
+    const int64_t nsurv = n >> P.lv[p].nlev;
+    T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D][MC] surviving rows, then [g][D][MC] owed panels
+    T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * PW : nullptr;
+    hipLaunchKernelGGL((cgps::halfsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT), lds, st, Dp, Fp, Gp, P.lv[p],
+                       owed_in, n_owed, spt_in, y, ld, n, w, xcrr, ld_x, yout, owed_out, partial + 2 * *pb);
+    *pb += g;
+    y = yout;
+    ld = MC;
+    owed_in = owed_out;
+    n_owed = g;
+    spt_in = TS >> P.lv[p].nlev;
+    if (spt_in < 1) spt_in = 1;
+  }
+  return CGPS_OK;
+}
+
+template <typename T, int D, int MC>
+int run_backsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* b, int ld_b, int w, T* x, int ld_o,
+                        T* buf0, T* buf1, hipStream_t st) {
+  constexpr int TSL = cgps::solve_m_tile_log2<MC>(), TS = 1 << TSL, NT = TS / 2;
+  Layout L;
+  make_layout(N, L);
+  SolvePasses P;
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL);
+  solve_m_attributes<T, D, MC>();
+  T* bufs[2] = {buf0, buf1};
+  const size_t lds = cgps::solve_m_lds_bytes<T, D, MC>();
+  const T* xc = nullptr;
+  for (int p = P.np - 1; p >= 0; --p) {
+    const int64_t n = P.rows[p], g = (n + TS - 1) / TS;
+    T* X = (p == 0) ? x : bufs[p & 1];
+    hipLaunchKernelGGL((cgps::backsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT), lds, st, Dp, Fp, Gp, P.lv[p],
+                       b, ld_b, xc, n, w, X, (p == 0) ? ld_o : MC);
+    xc = X;
+  }
+  return CGPS_OK;
+}
+
+enum class PanelOp { Half, Back, Solve };
+// nrhs >= 2 columns, panels of up to eight: halfsolve (y -> xcrr, mahal), backsolve (y = CRR -> x), solve (y -> x)
+template <typename T, int D, int MC>
+int run_panels(PanelOp op, const T* Dp, const T* Fp, const T* Gp, int64_t N, int nrhs, const T* y, T* out, char* ws,
+               size_t ws_bytes, double* mahal_out, hipStream_t st) {
+  const int chunks = (nrhs + MC - 1) / MC;
+  const PanelWs w = panel_ws(N, D, sizeof(T), MC, chunks);
+  const size_t crr = (op == PanelOp::Solve) ? align_up((size_t)N * D * MC * sizeof(T)) : 0;
+  if (ws_bytes < w.total + crr) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total + crr);
+  double* partial = reinterpret_cast<double*>(ws);
+  T* buf0 = reinterpret_cast<T*>(ws + w.partial_bytes);
+  T* buf1 = reinterpret_cast<T*>(ws + w.partial_bytes + w.buf_bytes);
+  T* xcrr_ws = reinterpret_cast<T*>(ws + w.total);
+  int64_t pb = 0;
+  for (int c0 = 0; c0 < nrhs; c0 += MC) {
+    const int wd = nrhs - c0 < MC ? nrhs - c0 : MC;
+    if (op == PanelOp::Half)
+      run_halfsolve_panel<T, D, MC>(Dp, Fp, Gp, N, y + c0, nrhs, wd, out + c0, nrhs, partial, &pb, buf0, buf1, st);
+    else if (op == PanelOp::Back)
+      run_backsolve_panel<T, D, MC>(Dp, Fp, Gp, N, y + c0, nrhs, wd, out + c0, nrhs, buf0, buf1, st);
+    else {
+      run_halfsolve_panel<T, D, MC>(Dp, Fp, Gp, N, y + c0, nrhs, wd, xcrr_ws, MC, partial, &pb, buf0, buf1, st);
+      run_backsolve_panel<T, D, MC>(Dp, Fp, Gp, N, xcrr_ws, MC, wd, out + c0, nrhs, buf0, buf1, st);
+    }
+  }
+  if (mahal_out) {
+    double* tmp = partial + 2 * pb;
+    hipLaunchKernelGGL(cgps::sum_partials_kernel, dim3(1), dim3(256), 0, st, partial, pb, tmp);
+    (void)hipMemcpyAsync(mahal_out, tmp, sizeof(double), hipMemcpyDeviceToDevice, st);
+  }
+  return check_launch("panel substitution sweeps");
+}
+
+template <typename T, int D>
+int run_panels_any(PanelOp op, const T* Dp, const T* Fp, const T* Gp, int64_t N, int nrhs, const T* y, T* out, char* ws,
+                   size_t ws_bytes, double* mahal_out, hipStream_t st) {
+  switch (panel_width(nrhs)) {
+    case 2: return run_panels<T, D, 2>(op, Dp, Fp, Gp, N, nrhs, y, out, ws, ws_bytes, mahal_out, st);
+    case 4: return run_panels<T, D, 4>(op, Dp, Fp, Gp, N, nrhs, y, out, ws, ws_bytes, mahal_out, st);
+    default: return run_panels<T, D, 8>(op, Dp, Fp, Gp, N, nrhs, y, out, ws, ws_bytes, mahal_out, st);
+  }
+}
 }  // namespace
 
 extern "C" {
 
-int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y,
+int cgps_solve_workspace_bytes(int64_t N, int d, int dtype, int op, int nrhs, size_t* bytes) {
+  if (bad_common(N, d) || !bytes || nrhs < 1) return fail(CGPS_ERR_ARG, "cgps_solve_workspace_bytes: bad argument");
+  if (nrhs == 1) return cgps_workspace_bytes(N, d, dtype, op, bytes);
+  if (d > 8) return fail(CGPS_ERR_UNSUPPORTED, "block size d=%d outside 1..8", d);
+  if (dtype != CGPS_F32 && dtype != CGPS_F64) return fail(CGPS_ERR_UNSUPPORTED, "dtype %d not supported", dtype);
+  if (op != CGPS_OP_HALFSOLVE && op != CGPS_OP_BACKSOLVE && op != CGPS_OP_SOLVE)
+    return fail(CGPS_ERR_ARG, "cgps_solve_workspace_bytes: op %d takes no right-hand sides", op);
+  const size_t s = dtype == CGPS_F32 ? 4 : 8;
+  const int mc = panel_width(nrhs);
+  const PanelWs w = panel_ws(N, d, s, mc, (nrhs + mc - 1) / mc);
+  *bytes = w.total + (op == CGPS_OP_SOLVE ? align_up((size_t)N * d * mc * s) : 0);
+  return CGPS_OK;
+}
+
+int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs, const void* y,
                    void* xcrr, void* ws, size_t ws_bytes, double* mahal_out, void* stream) {
-  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !xcrr || !ws)
-    return fail(CGPS_ERR_ARG, "cgps_halfsolve: null pointer or N < 1");
+  if (bad_common(N, d) || nrhs < 1 || !Dp || !Fp || !Gp || !y || !xcrr || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_halfsolve: null pointer, N < 1 or nrhs < 1");
   return dispatch(dtype, d, [&](auto t, auto dc) {
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
+    if (nrhs > 1)
+      return run_panels_any<T, D>(PanelOp::Half, (const T*)Dp, (const T*)Fp, (const T*)Gp, N, nrhs, (const T*)y, (T*)xcrr,
+                                  (char*)ws, ws_bytes, mahal_out, (hipStream_t)stream);
     return run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, (T*)xcrr, (char*)ws, ws_bytes,
                                mahal_out, (hipStream_t)stream);
   });
 }
 
-int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* ycrr,
-                   void* x, void* ws, size_t ws_bytes, void* stream) {
-  if (bad_common(N, d) || !Dp || !Fp || !Gp || !ycrr || !x || !ws)
-    return fail(CGPS_ERR_ARG, "cgps_backsolve: null pointer or N < 1");
+int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs,
+                   const void* ycrr, void* x, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || nrhs < 1 || !Dp || !Fp || !Gp || !ycrr || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_backsolve: null pointer, N < 1 or nrhs < 1");
   return dispatch(dtype, d, [&](auto t, auto dc) {
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
+    if (nrhs > 1)
+      return run_panels_any<T, D>(PanelOp::Back, (const T*)Dp, (const T*)Fp, (const T*)Gp, N, nrhs, (const T*)ycrr, (T*)x,
+                                  (char*)ws, ws_bytes, nullptr, (hipStream_t)stream);
     return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)ycrr, (T*)x, (char*)ws, ws_bytes,
                                (hipStream_t)stream);
   });
 }
 
-int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, const void* y, void* x,
-               void* ws, size_t ws_bytes, void* stream) {
-  if (bad_common(N, d) || !Dp || !Fp || !Gp || !y || !x || !ws)
-    return fail(CGPS_ERR_ARG, "cgps_solve: null pointer or N < 1");
+int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs, const void* y,
+               void* x, void* ws, size_t ws_bytes, void* stream) {
+  if (bad_common(N, d) || nrhs < 1 || !Dp || !Fp || !Gp || !y || !x || !ws)
+    return fail(CGPS_ERR_ARG, "cgps_solve: null pointer, N < 1 or nrhs < 1");
   return dispatch(dtype, d, [&](auto t, auto dc) {
     using T = decltype(t);
     constexpr int D = decltype(dc)::value;
+    if (nrhs > 1)
+      return run_panels_any<T, D>(PanelOp::Solve, (const T*)Dp, (const T*)Fp, (const T*)Gp, N, nrhs, (const T*)y, (T*)x,
+                                  (char*)ws, ws_bytes, nullptr, (hipStream_t)stream);
     const size_t crr = align_up((size_t)N * D * sizeof(T));
     if (ws_bytes < crr) return fail(CGPS_ERR_ARG, "workspace too small");
     T* xcrr = (T*)ws;

@@ -1,0 +1,297 @@
+// Substitution sweeps with SEVERAL right-hand sides at once: solve(decomp, Y[N, d, m]).
+// The reference's einsums carry a trailing "..." (cyclic_reduction.py:52-57, 76-84), so its
+// halfsolve / backhalfsolve / solve accept Y[N, d, m]; done column by column the 3 N d^2 s bytes of
+// the factor are read once per column and sweep.  Here a "vector" is a d x MC panel (MC = 2, 4 or
+// 8 columns, compile time; w <= MC of them real): one pass over the factor serves up to eight
+// columns, and the factor's share of the traffic falls from 3 d / (3 d + 2) to 3 d / (3 d + 2 m).
+//
+// Same scheme as cgps_solve_tile.h (tile of right-hand sides in LDS, several levels per launch,
+// rows stay in their level-0 slots, the reference's even/odd order and CRR layout), with the tile
+// size chosen so that the panel tile takes the LDS of the single-column tile: TS = 2^TSL rows,
+// TS / 2 threads.  Global vectors are [row][d][ld] with the caller's leading dimension ld (= nrhs
+// for its own arrays, = MC for workspace buffers), columns [0, w) of a panel valid.
+#pragma once
+#include "cgps_solve_tile.h"
+
+namespace cgps {
+
+template <int MC> constexpr int solve_m_tile_log2() { return MC <= 2 ? 9 : (MC <= 4 ? 8 : 7); }
+
+template <typename T, int D, int MC>
+struct Panel {
+  T v[D][MC];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) v[i][c] = T(0);
+  }
+  // global [d][ld], columns < w
+  __device__ __forceinline__ void load(const T* __restrict__ p, int ld, int w) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) v[i][c] = (c < w) ? p[(size_t)i * ld + c] : T(0);
+  }
+  __device__ __forceinline__ void store(T* __restrict__ p, int ld, int w) const {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c)
+        if (c < w) p[(size_t)i * ld + c] = v[i][c];
+  }
+  // LDS, dense [d][MC]
+  __device__ __forceinline__ void lds_load(const T* p) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) v[i][c] = p[i * MC + c];
+  }
+  __device__ __forceinline__ void lds_store(T* p) const {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) p[i * MC + c] = v[i][c];
+  }
+  __device__ __forceinline__ void sub(const Panel& o) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) v[i][c] -= o.v[i][c];
+  }
+  // v <- L^-1 v, every column
+  __device__ __forceinline__ void fwd(const Chol<T, D>& ch) {
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        T s = v[j][c];
+#pragma unroll
+        for (int q = 0; q < j; ++q) s = fmaT(-ch.l[j][q], v[q][c], s);
+        v[j][c] = s * ch.inv[j];
+      }
+  }
+  // v <- L^-T v
+  __device__ __forceinline__ void bwd(const Chol<T, D>& ch) {
+#pragma unroll
+    for (int j = D - 1; j >= 0; --j)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        T s = v[j][c];
+#pragma unroll
+        for (int q = j + 1; q < D; ++q) s = fmaT(-ch.l[q][j], v[q][c], s);
+        v[j][c] = s * ch.inv[j];
+      }
+  }
+  // v -= A x   /   v -= A^T x
+  __device__ __forceinline__ void gemm_sub(const T (&A)[D][D], const Panel& x) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        T s = v[i][c];
+#pragma unroll
+        for (int q = 0; q < D; ++q) s = fmaT(-A[i][q], x.v[q][c], s);
+        v[i][c] = s;
+      }
+  }
+  __device__ __forceinline__ void gemmT_sub(const T (&A)[D][D], const Panel& x) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        T s = v[i][c];
+#pragma unroll
+        for (int q = 0; q < D; ++q) s = fmaT(-A[q][i], x.v[q][c], s);
+        v[i][c] = s;
+      }
+  }
+  // v += A x
+  __device__ __forceinline__ void gemm_add(const T (&A)[D][D], const Panel& x) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        T s = v[i][c];
+#pragma unroll
+        for (int q = 0; q < D; ++q) s = fmaT(A[i][q], x.v[q][c], s);
+        v[i][c] = s;
+      }
+  }
+  __device__ __forceinline__ double sumsq() const {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int c = 0; c < MC; ++c) s += (double)v[i][c] * (double)v[i][c];
+    return s;
+  }
+};
+
+template <typename T, int D, int MC>
+constexpr size_t solve_m_lds_bytes() {
+  return ((size_t)(1 << solve_m_tile_log2<MC>()) + 1) * D * MC * sizeof(T) + 64 * sizeof(double);
+}
+
+// ---- forward sweep (cf. halfsolve_tile_kernel) ---------------------------------------------------
+// y_in [n][d][ld_y]; xcrr [N][d][ld_x] (CRR layout); y_out / owed_in / owed_out: workspace, ld = MC.
+template <typename T, int D, int MC>
+__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_tile_m_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int ld_y, int64_t n, int w,
+    T* __restrict__ xcrr, int ld_x, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
+  constexpr int DD = D * D, TS = 1 << solve_m_tile_log2<MC>(), NT = TS / 2, PW = D * MC;
+  using P = Panel<T, D, MC>;
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* ys = reinterpret_cast<T*>(solve_smem);                                   // [TS][D][MC]
+  T* owed = ys + (size_t)TS * PW;                                             // [D][MC]: sum_j G_j x_j of the tile's first rows
+  double* red = reinterpret_cast<double*>(owed + PW);
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * TS;
+  const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
+  for (int r = tid; r < n0; r += NT) {
+    P v;
+    v.load(y_in + (row0 + r) * (size_t)D * ld_y, ld_y, w);
+    const int64_t wn = row0 + r + 1;
+    if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {     // the last survivor of a tile of the previous pass
+      P o;
+      o.load(owed_in + (wn / spt_in) * (size_t)PW, MC, MC);
+      v.sub(o);
+    }
+    v.lds_store(ys + (size_t)r * PW);
+  }
+  for (int i = tid; i < PW; i += NT) owed[i] = T(0);
+  __syncthreads();
+  double mah = 0.0, zero = 0.0;
+  int nj = n0;
+  auto eliminate = [&](int j, int k, P& x) {
+    const int64_t g0 = row0 >> (j + 1);
+    T L[D][D];
+    Chol<T, D> c;
+    load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
+    chol_from_dense<T, D>(L, c);
+    x.fwd(c);
+    x.lds_store(ys + (size_t)(((2 * k + 1) << j) - 1) * PW);
+    x.store(xcrr + (lv.offD[j] + g0 + k) * (size_t)D * ld_x, ld_x, w);
+    mah += x.sumsq();
+    if (k == 0 && g0 >= 1) {                             // the previous tile's last row is this row's left neighbour
+      T G[D][D];
+      load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, G);
+      P o;
+      o.lds_load(owed);
+      o.gemm_add(G, x);
+      o.lds_store(owed);
+    }
+  };
+  for (int k = tid; k < ((nj + 1) >> 1); k += NT) {
+    P x;
+    x.lds_load(ys + (size_t)(2 * k) * PW);
+    eliminate(0, k, x);
+  }
+  __syncthreads();
+  for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
+    const int no = nj >> 1;
+    const int64_t g0 = row0 >> (j + 1);
+    const bool more = j + 1 < lv.nlev;
+    for (int k = tid; k < no; k += NT) {                 // y'_k = y_2k+1 - F_k x_k - G_k x_k+1
+      T M[D][D];
+      P x, yo;
+      T* slot = ys + (size_t)(((2 * k + 2) << j) - 1) * PW;
+      yo.lds_load(slot);
+      load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
+      x.lds_load(ys + (size_t)(((2 * k + 1) << j) - 1) * PW);
+      yo.gemm_sub(M, x);
+      if (2 * k + 2 < nj) {                              // right neighbour inside the tile
+        load_block<T, D>(Gp + (lv.offG[j] + g0 + k) * DD, M);
+        x.lds_load(ys + (size_t)(((2 * k + 3) << j) - 1) * PW);
+        yo.gemm_sub(M, x);
+      }
+      if (more && (k & 1) == 0) eliminate(j + 1, k >> 1, yo);
+      else yo.lds_store(slot);
+    }
+    __syncthreads();
+    nj = no;
+  }
+  if (y_out != nullptr) {                                // the tile's surviving rows: nj = n0 >> nlev of them
+    const int spt_out = TS >> lv.nlev;
+    for (int r = tid; r < nj; r += NT) {
+      P v;
+      v.lds_load(ys + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
+      v.store(y_out + ((size_t)blockIdx.x * spt_out + r) * PW, MC, MC);
+    }
+  }
+  if (owed_out != nullptr)
+    for (int i = tid; i < PW; i += NT) owed_out[(size_t)blockIdx.x * PW + i] = owed[i];
+  block_sum2<NT>(mah, zero, red);
+  if (tid == 0 && partial != nullptr) {
+    partial[2 * (size_t)blockIdx.x] = mah;
+    partial[2 * (size_t)blockIdx.x + 1] = 0.0;
+  }
+}
+
+// ---- backward sweep (cf. backsolve_tile_kernel) --------------------------------------------------
+// b [N][d][ld_b] in CRR layout; x_coarse: workspace (ld = MC), nullptr for the top pass; x_out [n][d][ld_o].
+template <typename T, int D, int MC>
+__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_tile_m_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ b, int ld_b, const T* __restrict__ x_coarse, int64_t n, int w, T* __restrict__ x_out, int ld_o) {
+  constexpr int DD = D * D, TS = 1 << solve_m_tile_log2<MC>(), NT = TS / 2, PW = D * MC;
+  using P = Panel<T, D, MC>;
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* xs = reinterpret_cast<T*>(solve_smem);                                   // [TS][D][MC]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * TS;
+  const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
+  P xleft;                                               // x of the previous tile's last row
+  xleft.zero();
+  if (x_coarse != nullptr) {                             // solution of the rows that survived this pass's levels
+    const int spt = TS >> lv.nlev;
+    if (blockIdx.x > 0) xleft.load(x_coarse + ((size_t)blockIdx.x * spt - 1) * PW, MC, MC);
+    for (int r = tid; r < (n0 >> lv.nlev); r += NT) {
+      P v;
+      v.load(x_coarse + ((size_t)blockIdx.x * spt + r) * PW, MC, MC);
+      v.lds_store(xs + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = lv.nlev - 1; j >= 0; --j) {
+    const int nj = n0 >> j;
+    if (nj >= 1) {
+      const int ne = (nj + 1) >> 1;
+      const int64_t g0 = row0 >> (j + 1);
+      for (int k = tid; k < ne; k += NT) {
+        T M[D][D];
+        P r, xo;
+        r.load(b + (lv.offD[j] + g0 + k) * (size_t)D * ld_b, ld_b, w);
+        if (2 * k + 1 < nj) {
+          load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
+          xo.lds_load(xs + (size_t)(((2 * k + 2) << j) - 1) * PW);
+          r.gemmT_sub(M, xo);
+        }
+        if (k >= 1) {
+          load_block<T, D>(Gp + (lv.offG[j] + g0 + k - 1) * DD, M);
+          xo.lds_load(xs + (size_t)(((2 * k) << j) - 1) * PW);
+          r.gemmT_sub(M, xo);
+        } else if (g0 >= 1) {                            // left neighbour = previous tile's last row
+          load_block<T, D>(Gp + (lv.offG[j] + g0 - 1) * DD, M);
+          r.gemmT_sub(M, xleft);
+        }
+        T L[D][D];
+        Chol<T, D> c;
+        load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
+        chol_from_dense<T, D>(L, c);
+        r.bwd(c);
+        r.lds_store(xs + (size_t)(((2 * k + 1) << j) - 1) * PW);
+      }
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n0; r += NT) {
+    P v;
+    v.lds_load(xs + (size_t)r * PW);
+    v.store(x_out + (row0 + r) * (size_t)D * ld_o, ld_o, w);
+  }
+}
+
+}  // namespace cgps

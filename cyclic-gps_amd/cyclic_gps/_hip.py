@@ -30,9 +30,10 @@ _SIGNATURES = {
     "cgps_mahal_logdet_levelwise": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),
     "cgps_decompose_step": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgps_decompose": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "cgps_halfsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "cgps_backsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "cgps_solve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cgps_solve_workspace_bytes": (_int, [_i64, _int, _int, _int, _int, ctypes.POINTER(_sz)]),
+    "cgps_halfsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cgps_backsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "cgps_solve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "cgps_logdet_factor": (_int, [_vp, _i64, _int, _int, _vp, _sz, _vp, _vp]),
     "cgps_inverse_blocks": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "cgps_mahal_logdet_adjoint": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
@@ -109,18 +110,21 @@ def level_layout(N):
 
 
 @functools.lru_cache(maxsize=2048)
-def _workspace_bytes(N, d, dtc, op):
+def _workspace_bytes(N, d, dtc, op, nrhs=1):
     b = _sz(0)
-    check(lib().cgps_workspace_bytes(N, d, dtc, op, ctypes.byref(b)))
+    if nrhs == 1:
+        check(lib().cgps_workspace_bytes(N, d, dtc, op, ctypes.byref(b)))
+    else:
+        check(lib().cgps_solve_workspace_bytes(N, d, dtc, op, nrhs, ctypes.byref(b)))
     return b.value
 
 
 _ws_cache = {}
 
 
-def workspace(N, d, dt, op, device):
+def workspace(N, d, dt, op, device, nrhs=1):
     """A cached scratch tensor of the size the library asks for (torch owns the memory)."""
-    nbytes = _workspace_bytes(int(N), int(d), dtype_code(dt), int(op))
+    nbytes = _workspace_bytes(int(N), int(d), dtype_code(dt), int(op), int(nrhs))
     key = (device, torch.cuda.current_stream().cuda_stream)
     cur = _ws_cache.get(key)
     if cur is None or cur.numel() < nbytes:

@@ -194,6 +194,13 @@ def _outer(a, b):
     return a.unsqueeze(-1) * b.unsqueeze(-2)
 
 
+def _pair(a, b):
+    """sum over the right-hand-side columns of a_c b_c^T per block row: [N, d] or [N, d, ...] -> [N, d, d]"""
+    if a.dim() == 2:
+        return _outer(a, b)
+    return a.reshape(a.shape[0], a.shape[1], -1) @ b.reshape(b.shape[0], b.shape[1], -1).transpose(-1, -2)
+
+
 _side_streams = {}
 
 
@@ -272,9 +279,9 @@ class _SolveFn(torch.autograd.Function):
         a = _solve_raw(ctx.dec, g.contiguous())
         gR = gO = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            aw = _outer(a, w)
+            aw = _pair(a, w)
             gR = -0.5 * (aw + aw.transpose(-1, -2))
-            gO = -(_outer(a[1:], w[:-1]) + _outer(w[1:], a[:-1]))
+            gO = -(_pair(a[1:], w[:-1]) + _pair(w[1:], a[:-1]))
         return gR, gO, a, None
 
 
@@ -298,8 +305,19 @@ def _mahal_and_det(Rs, Os, x, levelwise):
 # ----------------------------------------------------------------------------
 # operations on a stored factor
 # ----------------------------------------------------------------------------
+def _rhs(y, N, d, dt):
+    """y [N, d] or [N, d, ...] (the reference's einsums carry a trailing "...", :52-57) as a contiguous
+    [N, d, m] device tensor, plus m and the trailing shape to restore."""
+    v = _stage(y, dt)
+    tail = tuple(v.shape[2:])
+    m = 1
+    for s in tail:
+        m *= s
+    return v.reshape(N, d, m), m, tail
+
+
 def halfsolve(decomp, y):
-    """L^-1 (T y) as the per-level list ("CRR layout")   (reference :312-338)."""
+    """L^-1 (T y) as the per-level list ("CRR layout")   (reference :312-338).  y: [N, d] or [N, d, m]."""
     xs, _ = _halfsolve(decomp, y, want_mahal=False)
     return xs
 
@@ -307,14 +325,15 @@ def halfsolve(decomp, y):
 def _halfsolve(decomp, y, want_mahal):
     Dp, Fp, Gp, N, d, like = _packed(decomp)
     dev, dt = Dp.device, Dp.dtype
-    v = _stage(y, dt).reshape(N, d)
-    xcrr = torch.empty((N, d), dtype=dt, device=dev)
+    v, m, tail = _rhs(y, N, d, dt)
+    xcrr = torch.empty((N, d, m), dtype=dt, device=dev)
     mah = torch.empty(1, dtype=torch.float64, device=dev) if want_mahal else None
-    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_HALFSOLVE, dev)
+    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_HALFSOLVE, dev, nrhs=m)
     _hip.check(_hip.lib().cgps_halfsolve(
-        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), _hip.ptr(v), _hip.ptr(xcrr),
+        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), m, _hip.ptr(v), _hip.ptr(xcrr),
         _hip.ptr(ws), nbytes, _hip.ptr(mah), _hip.stream_ptr()))
     ms, offD, _, _ = _hip.level_layout(N)
+    xcrr = xcrr.reshape((N, d) + tail)
     xs = [_back(xcrr[offD[i]:offD[i + 1]], y) for i in range(len(ms))]
     return xs, mah
 
@@ -324,14 +343,16 @@ def backhalfsolve(decomp, ycrr):
     Dp, Fp, Gp, N, d, like = _packed(decomp)
     dev, dt = Dp.device, Dp.dtype
     src = ycrr[0]
-    b = torch.cat([_stage(t, dt).reshape(-1, d) for t in ycrr], dim=0)
+    tail = tuple(src.shape[2:])
+    b = torch.cat([_stage(t, dt).reshape(t.shape[0], d, -1) for t in ycrr], dim=0).contiguous()
     assert b.shape[0] == N
-    x = torch.empty((N, d), dtype=dt, device=dev)
-    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_BACKSOLVE, dev)
+    m = b.shape[2]
+    x = torch.empty((N, d, m), dtype=dt, device=dev)
+    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_BACKSOLVE, dev, nrhs=m)
     _hip.check(_hip.lib().cgps_backsolve(
-        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), _hip.ptr(b), _hip.ptr(x),
+        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), m, _hip.ptr(b), _hip.ptr(x),
         _hip.ptr(ws), nbytes, _hip.stream_ptr()))
-    return _back(x, src)
+    return _back(x.reshape((N, d) + tail), src)
 
 
 def _decomp_inputs(decomp):
@@ -340,7 +361,8 @@ def _decomp_inputs(decomp):
 
 
 def solve(decomp, y):
-    """J^-1 y   (reference :441-444).  Differentiable in y and in the Rs / Os the factor came from."""
+    """J^-1 y   (reference :441-444); y: [N, d] or [N, d, m] (up to eight columns share one read of the
+    factor).  Differentiable in y and in the Rs / Os the factor came from."""
     Rs, Os = _decomp_inputs(decomp)
     if _needs_grad(Rs, Os, y):
         if Rs is None:       # only y carries grad: J^-1 is a constant symmetric operator
@@ -353,13 +375,13 @@ def solve(decomp, y):
 def _solve_raw(decomp, y):
     Dp, Fp, Gp, N, d, like = _packed(decomp)
     dev, dt = Dp.device, Dp.dtype
-    v = _stage(y, dt).reshape(N, d)
-    x = torch.empty((N, d), dtype=dt, device=dev)
-    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_SOLVE, dev)
+    v, m, tail = _rhs(y, N, d, dt)
+    x = torch.empty((N, d, m), dtype=dt, device=dev)
+    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_SOLVE, dev, nrhs=m)
     _hip.check(_hip.lib().cgps_solve(
-        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), _hip.ptr(v), _hip.ptr(x),
+        _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp), N, d, _hip.dtype_code(dt), m, _hip.ptr(v), _hip.ptr(x),
         _hip.ptr(ws), nbytes, _hip.stream_ptr()))
-    return _back(x, y)
+    return _back(x.reshape((N, d) + tail), y)
 
 
 def det(decomp):

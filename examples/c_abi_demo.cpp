@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
   if (info != 0 || std::fabs(out[0] - mahal) > 1e-9 * std::fabs(mahal) || std::fabs(out[1] - logdet) > 1e-9 * std::fabs(logdet)) ++bad;
 
   CGPS_OK_(cgps_decompose(dR, dO, N, d, CGPS_F64, dD, dF, dG, ws, ws_bytes, dinfo, st));
-  CGPS_OK_(cgps_solve(dD, dF, dG, N, d, CGPS_F64, db, dx, ws, ws_bytes, st));
+  CGPS_OK_(cgps_solve(dD, dF, dG, N, d, CGPS_F64, /*nrhs*/ 1, db, dx, ws, ws_bytes, st));
   CGPS_OK_(cgps_logdet_factor(dD, N, d, CGPS_F64, ws, ws_bytes, dout, st));
   std::vector<double> x(N * d);
   HIP_OK(hipMemcpyAsync(x.data(), dx, x.size() * 8, hipMemcpyDeviceToHost, st));

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CGPS_VERSION 100
+#define CGPS_VERSION 200
 
 enum { CGPS_F32 = 0, CGPS_F64 = 1 };
 
@@ -92,17 +92,25 @@ int cgps_decompose_step(const void* Rs, const void* Os, int64_t n, int d, int dt
 int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype,
                    void* Dp, void* Fp, void* Gp, void* ws, size_t ws_bytes, int* info, void* stream);
 
+/* Right-hand sides: the reference's einsums carry a trailing "..." (cyclic_reduction.py:52-57,
+ * 76-84), so halfsolve / backhalfsolve / solve take y[N][d] or Y[N][d][m].  nrhs = m (1 for a plain
+ * vector); all vectors are [N][d][nrhs], C-contiguous.  For nrhs > 1 the factor is read once per
+ * sweep and per panel of up to eight columns (csrc/cgps_solve_tile_m.h) instead of once per column;
+ * size the workspace with cgps_solve_workspace_bytes(). */
+int cgps_solve_workspace_bytes(int64_t N, int d, int dtype, int op, int nrhs, size_t* bytes);
+
 /* halfsolve(decomp, y) -> L^-1 T y in CRR layout              cyclic_reduction.py:312-338
- * mahal_out (optional, device double) receives ||L^-1 T y||^2 = mahal(decomp, y), :461-467. */
-int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+ * mahal_out (optional, device double) receives ||L^-1 T y||^2 = mahal(decomp, y), :461-467
+ * (summed over all nrhs columns, like the reference's torch.sum). */
+int cgps_halfsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs,
                    const void* y, void* xcrr, void* ws, size_t ws_bytes, double* mahal_out, void* stream);
 
 /* backhalfsolve(decomp, ycrr) -> T^T L^-T ycrr, natural order  cyclic_reduction.py:341-377 */
-int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs,
                    const void* ycrr, void* x, void* ws, size_t ws_bytes, void* stream);
 
 /* solve(decomp, y) -> J^-1 y                                   cyclic_reduction.py:441-444 */
-int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype,
+int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs,
                const void* y, void* x, void* ws, size_t ws_bytes, void* stream);
 
 /* det(decomp) -> log|J| = 2 sum log diag(D)                    cyclic_reduction.py:447-458 */

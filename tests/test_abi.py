@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_hip.exported_symbols()) == declared
-    assert _hip.lib().cgps_version() == 100
+    assert _hip.lib().cgps_version() == 200
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 6, 31, 32, 33, 502, 1024, 2 ** 20, 2 ** 24 + 5])
@@ -57,7 +57,7 @@ def test_workspace_and_argument_errors():
     # null pointers are rejected before anything is launched
     assert lib.cgps_mahal_logdet(None, None, None, 8, 4, _hip.F64, None, 0, None, None, None) == 1
     assert lib.cgps_decompose(None, None, 8, 4, _hip.F64, None, None, None, None, 0, None, None) == 1
-    assert lib.cgps_solve(None, None, None, 8, 4, _hip.F64, None, None, None, 0, None) == 1
+    assert lib.cgps_solve(None, None, None, 8, 4, _hip.F64, 1, None, None, None, 0, None) == 1
 
 
 def test_surface_names_match_reference_module():

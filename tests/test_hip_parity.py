@@ -228,3 +228,70 @@ def test_folded_final_stage_never_reads_stale_records():
             assert abs(ld - logdet) <= 1e-10 * abs(logdet)
             assert abs(ld - ld_ref) <= 1e-11 * abs(ld_ref) and abs(m - m_ref) <= 1e-9 * abs(m_ref)
         assert (m, ld) == first[k], (k, m, ld, first[k])
+
+
+@pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float32), (4, torch.float64),
+                                     (5, torch.float64), (8, torch.float32)],
+                         ids=["d1f64", "d2f64", "d3f32", "d4f64", "d5f64", "d8f32"])
+@pytest.mark.parametrize("m", [2, 3, 4, 7, 8, 11])
+def test_batched_right_hand_sides_against_oracle_columns(d, dtype, m):
+    """solve / halfsolve / backhalfsolve / mahal with Y[N, d, m] (the reference's einsums carry a trailing
+    "...", cyclic_reduction.py:52-57): every column equals the oracle's single-column result.  Sizes
+    around the panel tiles (128 / 256 / 512 rows), several passes, ragged tiles."""
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=3e-4, atol=3e-4)
+    for n in (1, 2, 5, 127, 128, 129, 257, 1000, 4097, 70001):
+        Rs, Os, b, _, _ = _util.conditioned_system(n, d, seed=31 + n + m)
+        g = torch.Generator().manual_seed(n + 7 * m)
+        Y = torch.randn(n, d, m, dtype=torch.float64, generator=g)
+        ref_dec = O.decompose(Rs, Os)
+        dec = cr.decompose(Rs.to(dtype).cuda(), Os.to(dtype).cuda())
+        Yd = Y.to(dtype).cuda()
+        X = cr.solve(dec, Yd)
+        assert X.shape == (n, d, m)
+        half = cr.halfsolve(dec, Yd)
+        back = cr.backhalfsolve(dec, half)
+        mah = float(cr.mahal(dec, Yd))
+        ref_mah = 0.0
+        for c in range(m):
+            ref_half = O.halfsolve(ref_dec, Y[:, :, c])
+            ref_x = O.backhalfsolve(ref_dec, ref_half)
+            ref_mah += float(sum((h ** 2).sum() for h in ref_half))
+            np.testing.assert_allclose(_np(X[:, :, c]).astype(np.float64), _np(ref_x), err_msg="n=%d c=%d" % (n, c), **tol)
+            np.testing.assert_allclose(_np(back[:, :, c]).astype(np.float64), _np(ref_x), err_msg="n=%d c=%d" % (n, c), **tol)
+            np.testing.assert_allclose(np.concatenate([_np(h[:, :, c]) for h in half]).astype(np.float64),
+                                       np.concatenate([_np(h) for h in ref_half]), err_msg="n=%d c=%d" % (n, c), **tol)
+        assert abs(mah - ref_mah) <= (1e-9 if dtype == torch.float64 else 1e-3) * max(1.0, abs(ref_mah))
+    # trailing shape [N, d, 2, 3] behaves like m = 6
+    Y4 = torch.randn(300, d, 2, 3, dtype=torch.float64, generator=g)
+    Rs, Os, _, _, _ = _util.conditioned_system(300, d, seed=5)
+    dec = cr.decompose(Rs.to(dtype).cuda(), Os.to(dtype).cuda())
+    X4 = cr.solve(dec, Y4.to(dtype).cuda())
+    assert X4.shape == Y4.shape
+    np.testing.assert_allclose(_np(X4[:, :, 1, 2]).astype(np.float64), _np(O.solve(O.decompose(Rs, Os), Y4[:, :, 1, 2])), **tol)
+
+
+def test_batched_solve_full_size_and_gradients():
+    """Config-2 size: eight planted solutions at once; and autograd through solve with Y[N, d, m]."""
+    n, d, m = 2 ** 20, 4, 8
+    Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, device="cuda")
+    dec = cr.decompose(Rs, Os)
+    scale = torch.arange(1, m + 1, dtype=torch.float64, device="cuda")
+    X = cr.solve(dec, b[:, :, None] * scale)
+    assert float((X - x_true[:, :, None] * scale).abs().max()) <= 1e-8
+    # gradients: sum_c u_c^T J^-1 y_c against the same thing column by column
+    n = 1000
+    Rs, Os, _, _, _ = _util.conditioned_system(n, 3, device="cuda", seed=3)
+    Y = torch.randn(n, 3, 4, dtype=torch.float64, device="cuda")
+    U = torch.randn(n, 3, 4, dtype=torch.float64, device="cuda")
+    grads = []
+    for batched in (True, False):
+        R, Oo, Yg = Rs.clone().requires_grad_(True), Os.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+        dec = cr.decompose(R, Oo)
+        if batched:
+            s = (U * cr.solve(dec, Yg)).sum()
+        else:
+            s = sum((U[:, :, c] * cr.solve(dec, Yg[:, :, c])).sum() for c in range(4))
+        s.backward()
+        grads.append((R.grad.clone(), Oo.grad.clone(), Yg.grad.clone()))
+    for a, bb in zip(*grads):
+        np.testing.assert_allclose(_np(a), _np(bb), rtol=1e-9, atol=1e-10)
