@@ -259,9 +259,23 @@ def extra_measurements(dev):
                "log_likelihood_us": _time_cuda(lambda: leg.log_likelihood(m, ts, xs), 10) * 1e6,
                "insample_posterior_us": _time_cuda(lambda: leg.insample_posterior(m, ts, xs), 10) * 1e6,
                "ll_rel_err_vs_reference": abs(float(ll) - float(g["ll"])) / abs(float(g["ll"]))}
-        # the same evaluation with a gradient wanted: operand assembly by batched torch ops (autograd)
-        mg = leg.LEGMatrices(t("N").requires_grad_(True), t("R"), t("B"), t("Lambda"))
+        # the same evaluation with a gradient wanted (operands from cgps_peg_precision through its
+        # analytic adjoint, csrc/cgps_leg.h), and a whole training step: forward + backward to the parameters
+        mg = leg.LEGMatrices(*(t(k).requires_grad_(True) for k in ("N", "R", "B", "Lambda")))
         res["log_likelihood_with_grad_graph_us"] = _time_cuda(lambda: leg.log_likelihood(mg, ts, xs), 5) * 1e6
+
+        def train_step():
+            leg.log_likelihood(mg, ts, xs).backward()
+            for p_ in (mg.N, mg.R, mg.B, mg.Lambda):
+                p_.grad = None
+        res["log_likelihood_fwd_bwd_us"] = _time_cuda(train_step, 5) * 1e6
+        from cyclic_gps import predict
+        tt = torch.from_numpy(g["target_ts"]).to(dev) if "target_ts" in g.files else ts
+        pm = predict.make_predictions(m, ts, xs, tt)[0]
+        res["make_predictions_us"] = _time_cuda(lambda: predict.make_predictions(m, ts, xs, tt), 5) * 1e6
+        res["make_predictions_targets"] = int(tt.shape[0])
+        if "pred_mean" in g.files:
+            res["prediction_mean_max_abs_err_vs_reference"] = float((pm.cpu() - torch.from_numpy(g["pred_mean"])).abs().max())
         if "post_mean" in g.files:
             res["posterior_mean_max_abs_err_vs_reference"] = float(
                 (mean.cpu() - torch.from_numpy(g["post_mean"])).abs().max())

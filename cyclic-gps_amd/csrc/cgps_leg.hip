@@ -24,4 +24,19 @@ int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtyp
   });
 }
 
+int cgps_peg_precision_adjoint(const void* ts, const void* G, int64_t N, int d, int dtype, const void* gRs,
+                               const void* gOs, void* gG_partial, void* gtau, void* stream) {
+  if (bad_common(N, d) || N < 2 || !ts || !G || !gRs || !gOs || !gG_partial)
+    return fail(CGPS_ERR_ARG, "cgps_peg_precision_adjoint: null pointer or N < 2");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const int64_t nb = (N - 1 + cgps::LEG_THREADS - 1) / cgps::LEG_THREADS;
+    hipLaunchKernelGGL((cgps::peg_precision_adjoint_kernel<T, D>), dim3((unsigned)nb), dim3(cgps::LEG_THREADS), 0,
+                       (hipStream_t)stream, (const T*)ts, (const T*)G, N, (const T*)gRs, (const T*)gOs, (T*)gG_partial,
+                       (T*)gtau);
+    return check_launch("peg_precision_adjoint");
+  });
+}
+
 }  // extern "C"

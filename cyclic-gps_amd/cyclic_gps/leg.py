@@ -71,13 +71,52 @@ def _peg_precision_hip(ts, G):
     return Rs, Os
 
 
+class _PegPrecisionFn(torch.autograd.Function):
+    """cgps_peg_precision with its analytic adjoint (cgps_peg_precision_adjoint, csrc/cgps_leg.h): a
+    training step assembles its operands with the same kernel as an evaluation."""
+
+    @staticmethod
+    def forward(ctx, ts, G):
+        ctx.save_for_backward(ts, G)
+        Rs, Os = _peg_precision_hip(ts.detach(), G.detach())
+        ctx.mark_non_differentiable()
+        return Rs, Os
+
+    @staticmethod
+    def backward(ctx, gRs, gOs):
+        from . import _hip
+        ts, G = ctx.saved_tensors
+        n, d = ts.shape[0], G.shape[0]
+        if n < 2:
+            return None, torch.zeros_like(G)
+        tsd = ts.detach().to(G.dtype).contiguous()
+        gRs = torch.zeros(n, d, d, dtype=G.dtype, device=G.device) if gRs is None else gRs.to(G.dtype).contiguous()
+        gOs = torch.zeros(n - 1, d, d, dtype=G.dtype, device=G.device) if gOs is None else gOs.to(G.dtype).contiguous()
+        nb = (n - 1 + 63) // 64
+        part = torch.empty(nb, d, d, dtype=G.dtype, device=G.device)
+        want_ts = ctx.needs_input_grad[0]
+        gtau = torch.empty(n - 1, dtype=G.dtype, device=G.device) if want_ts else None
+        _hip.check(_hip.lib().cgps_peg_precision_adjoint(
+            _hip.ptr(tsd), _hip.ptr(G.detach().contiguous()), n, d, _hip.dtype_code(G.dtype), _hip.ptr(gRs), _hip.ptr(gOs),
+            _hip.ptr(part), _hip.ptr(gtau), _hip.stream_ptr()))
+        gts = None
+        if want_ts:
+            z = gtau.new_zeros(1)
+            gts = (torch.cat([z, gtau]) - torch.cat([gtau, z])).to(ts.dtype)
+        return gts, part.sum(0)
+
+
 def peg_precision(ts, G):
     """Diagonal and lower off-diagonal blocks of the PEG prior precision (models.py:181-239).
-    On the GPU, when no gradient is wanted, one HIP kernel; otherwise batched torch ops (autograd)."""
+    On the GPU one HIP kernel, differentiable in G and ts through its analytic adjoint (a second
+    kernel); on CPU tensors batched torch ops."""
     d = G.shape[0]
     wants_grad = torch.is_grad_enabled() and (G.requires_grad or ts.requires_grad)
-    if G.is_cuda and ts.is_cuda and not wants_grad and 1 <= d <= 8 and G.dtype in (torch.float32, torch.float64):
-        return _peg_precision_hip(ts, G)
+    if G.is_cuda and ts.is_cuda and 1 <= d <= 8 and G.dtype in (torch.float32, torch.float64):
+        if wants_grad and os.environ.get("CGPS_LEG_TORCH_ASSEMBLY") != "1":
+            return _PegPrecisionFn.apply(ts, G)
+        if not wants_grad:
+            return _peg_precision_hip(ts, G)
     eye = torch.eye(d, dtype=G.dtype, device=G.device)
     dt = ts[1:] - ts[:-1]
     E = torch.matrix_exp(-0.5 * G.unsqueeze(0) * dt.reshape(-1, 1, 1))

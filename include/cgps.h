@@ -141,6 +141,15 @@ int cgps_mahal_logdet_adjoint(void* Sd, void* So, const void* w, int64_t N, int 
 int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtype,
                        void* Rs, void* Os, int* info, void* stream);
 
+/* Adjoint of cgps_peg_precision in G and in the time gaps (training through the assembly; what
+ * autograd computes through models.py:181-239 for LEGFamily.training_step, models.py:374-381).
+ * gRs[N][d][d], gOs[N-1][d][d]: d loss / d Rs, d loss / d Os.  One lane per time gap, 64 gaps per
+ * workgroup; gG_partial[ceil((N-1)/64)][d][d] receives each workgroup's share of d loss / d G
+ * (the caller adds them up: a few d x d blocks, deterministic order); gtau[N-1] (may be NULL)
+ * receives d loss / d (t_{i+1} - t_i).  N >= 2.  No workspace. */
+int cgps_peg_precision_adjoint(const void* ts, const void* G, int64_t N, int d, int dtype,
+                               const void* gRs, const void* gOs, void* gG_partial, void* gtau, void* stream);
+
 /* ---- time-axis sharding (one shard per GPU / rank) -----------------------------------------
  * The reference has no distributed code; this is the multi-GPU form BASELINE.json asks for.
  * A shard is n_loc consecutive block rows: Rs[n_loc], Os[n_loc-1] (couplings INSIDE the shard),

@@ -179,3 +179,51 @@ def test_make_predictions_fp32_within_1e4():
     pm, _ = predict.make_predictions(m32, ts.float(), xs.float(), target_ts.float())
     err = np.abs(pm.cpu().double().numpy() - g["pred_mean"]).max()
     assert err <= 1e-4 * max(1.0, np.abs(g["pred_mean"]).max()), err
+
+
+# ---- adjoint of the operand assembly (cgps_peg_precision_adjoint) ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_hip_assembly_adjoint_against_torch_autograd(d, dtype):
+    """d loss / d G and d loss / d ts of the assembly kernel's analytic adjoint against autograd through
+    the batched torch restatement (matrix_exp + two solves per gap), random upstream gradients."""
+    gen = torch.Generator().manual_seed(90 + d)
+    Nm = 0.6 * torch.randn(d, d, generator=gen, dtype=torch.float64).tril()
+    Rm = 0.4 * torch.randn(d, d, generator=gen, dtype=torch.float64).tril(-1)
+    G = Nm @ Nm.T + Rm - Rm.T + 1e-5 * torch.eye(d, dtype=torch.float64)
+    gaps = 10.0 ** (torch.rand(300, generator=gen, dtype=torch.float64) * 1.5 - 0.3)       # 0.5 .. 16
+    ts = torch.cat([torch.zeros(1, dtype=torch.float64), gaps.cumsum(0)])
+    uR = torch.randn(301, d, d, generator=gen, dtype=torch.float64)
+    uO = torch.randn(300, d, d, generator=gen, dtype=torch.float64)
+    res = {}
+    for how in ("torch", "hip"):
+        os.environ["CGPS_LEG_TORCH_ASSEMBLY"] = "1" if how == "torch" else "0"
+        try:
+            dt_ = torch.float64 if how == "torch" else dtype
+            Gd = G.to(dt_).cuda().requires_grad_(True)
+            td = ts.to(dt_).cuda().requires_grad_(True)
+            Rs, Os = leg.peg_precision(td, Gd)
+            ((Rs * uR.to(dt_).cuda()).sum() + (Os * uO.to(dt_).cuda()).sum()).backward()
+            res[how] = (Gd.grad.double().cpu().numpy(), td.grad.double().cpu().numpy())
+        finally:
+            os.environ.pop("CGPS_LEG_TORCH_ASSEMBLY", None)
+    scale = max(1.0, np.abs(res["torch"][0]).max())
+    tol = 1e-8 if dtype == torch.float64 else 5e-3
+    assert np.abs(res["hip"][0] - res["torch"][0]).max() <= tol * scale
+    assert np.abs(res["hip"][1] - res["torch"][1]).max() <= tol * max(1.0, np.abs(res["torch"][1]).max())
+
+
+@pytest.mark.gpu
+def test_log_likelihood_gradients_match_reference_autograd():
+    """A training step through the whole harness on the device (assembly kernel + its adjoint, fused
+    solve + log-det + its adjoint) against the parameter gradients the reference's autograd gives
+    through its own cyclic reduction (tests/golden/leg_co2like.npz: gN, gR, gB, gLambda)."""
+    g, m, ts, xs = _load("leg_co2like", device="cuda")
+    N, R, B, Lam = (t.clone().requires_grad_(True) for t in (m.N, m.R, m.B, m.Lambda))
+    ll = leg.log_likelihood(leg.LEGMatrices(N, R, B, Lam), ts, xs)
+    assert abs(float(ll) - float(g["grad_ll"])) <= 1e-8 * abs(float(g["grad_ll"]))
+    ll.backward()
+    for got, key in ((N.grad.tril(), "gN"), (R.grad.tril(-1), "gR"), (B.grad, "gB"), (Lam.grad.tril(), "gLambda")):
+        ref = g[key]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(ref).max()), err_msg=key)
