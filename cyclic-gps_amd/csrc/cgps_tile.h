@@ -445,7 +445,7 @@ constexpr int FOLD_SLOTS = 1024;
 #define CGPS_FOLD_GROUP 16
 #endif
 constexpr int FOLD_GROUP = CGPS_FOLD_GROUP; // stage-1 records per group (fold_final, below)
-constexpr int FOLD_MAX_GROUPS = 16;         // <= 256 stage-1 workgroups
+constexpr int FOLD_MAX_GROUPS = 64;         // <= 1024 stage-1 workgroups per launch
 // [slot][0]: arrivals of the group leaders; [slot][1 + g]: arrivals of group g's workgroups
 static __device__ unsigned int g_fold_counter[FOLD_SLOTS][1 + FOLD_MAX_GROUPS];
 
@@ -660,8 +660,10 @@ template <typename T, int D> constexpr int stage1_min_waves() {
 struct FoldArgs {
   int slot;                        // this launch's arrival counters: g_fold_counter[slot][..]
   void* group_records;             // [groups] records of the second level (workspace)
-  double* out2;
+  double* out2;                    // whole system: {mahal, logdet} and info ...
   int* info;
+  void* shard_record;              // ... or one shard of a larger system (non-null): its single record
+  double* shard_partial;           //     and its {sum of squares, sum of log pivots, fail, 0}
 };
 template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL = false>
 __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
@@ -752,21 +754,23 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
   CGPS_KSTAMP(3);
   if constexpr (FOLD) {
-    static_assert(NW == 2 * NT, "fold_final runs the record stages with the wide workgroup");
     // Two levels inside the launch.  The workgroups of a GROUP of FOLD_GROUP consecutive tiles
     // arrive on the group's counter; the one that arrives last reduces the group's records to
     // one (four narrow levels, ~7 KB pulled through one CU) and arrives on the launch's counter;
-    // the group leader that arrives last there reduces the <= 16 group records, eliminates the
-    // last row and writes out2 / info.  Against ONE workgroup taking all 256 records: the 115 KB
-    // copy through a single CU (~3 us) becomes sixteen parallel 7 KB copies, and the two widest
-    // levels (128 and 64 eliminations, 2.3 + 1.3 us) become narrow ones (0.85 us).
+    // the group leader that arrives last there reduces the group records (<= 64), and either
+    // eliminates the last row and writes out2 / info (whole system) or leaves the shard's single
+    // record and partial result (one shard of a larger system).  Against ONE workgroup taking all
+    // 256 records in a second launch: the 115 KB copy through a single CU (~3 us) becomes sixteen
+    // parallel 7 KB copies, and the two widest levels (128 and 64 eliminations, 2.3 + 1.3 us)
+    // become narrow ones (0.85 us).
     // Hand-off (MI355X guide, inter-workgroup communication): every store of a record or
     // partial result is a write-through store issued by wave 0; wave 0 drains them, ONE lane
-    // arrives with one returning agent-scope atomic; the last arriver reads the handed-off bytes
-    // with coherent (sc1) loads ONLY (COH) -- or, for block sizes whose copy is not vectorised,
-    // takes an agent-scope acquire and uses plain loads; the workgroup barrier holds the other
-    // waves until the arrival has returned (and the invalidate has completed).
-    constexpr bool COH = (D * D) % Vec16<T>::N == 0;
+    // arrives with one returning agent-scope atomic.  With one workgroup per CU (NW = 2 NT) and a
+    // vectorised copy the last arriver reads the handed-off bytes with coherent (sc1) loads ONLY
+    // (COH: the form the guide lists as measured for exactly this shape); otherwise it takes an
+    // agent-scope acquire and uses plain loads.  The workgroup barrier holds the other waves until
+    // the arrival has returned (and the invalidate has completed).
+    constexpr bool COH = (NW == 2 * NT) && (D * D) % Vec16<T>::N == 0;
     using RL = RecordLayout<T, D>;
     int* last_flag = sm.sfail + 1;
     const unsigned grp = blockIdx.x / FOLD_GROUP, ngrp = (gridDim.x + FOLD_GROUP - 1) / FOLD_GROUP;
@@ -799,10 +803,17 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
       const bool fin = arrive(&g_fold_counter[fold.slot][0], ngrp);
       CGPS_KSTAMP(6);
       if (fin) {
-        record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr, (double*)nullptr,
-                                                                 partial, (int64_t)gridDim.x + ngrp, fold.out2, fold.info,
-                                                                 (int64_t)C * NT * FOLD_GROUP, N, (int64_t)RL::STRIDE,
-                                                                 (int64_t)PARTIAL_STRIDE);
+        if (fold.shard_record != nullptr)
+          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, false, COH>(smem, 0u, grec, (int64_t)ngrp, 1,
+                                                                    reinterpret_cast<T*>(fold.shard_record), fold.shard_partial,
+                                                                    partial, (int64_t)gridDim.x + ngrp, (double*)nullptr,
+                                                                    (int*)nullptr, (int64_t)C * NT * FOLD_GROUP, N,
+                                                                    (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+        else
+          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr,
+                                                                   (double*)nullptr, partial, (int64_t)gridDim.x + ngrp,
+                                                                   fold.out2, fold.info, (int64_t)C * NT * FOLD_GROUP, N,
+                                                                   (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
         CGPS_KSTAMP(7);
       }
     }
@@ -1011,9 +1022,10 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
     if (partial_in != nullptr) {           // last launch of a shard: fold in the partial results of the earlier ones
       for (int64_t i = tid; i < n_partial; i += NT) {
         const double* p = partial_in + pstride * i;
-        mah += p[0];
-        logp += p[1];
-        if (p[2] != 0.0 && (fcode == 0 || (int)p[2] < fcode)) fcode = (int)p[2];
+        const double p0 = load_coh<INL>(p), p1 = load_coh<INL>(p + 1), p2 = load_coh<INL>(p + 2);
+        mah += p0;
+        logp += p1;
+        if (p2 != 0.0 && (fcode == 0 || (int)p2 < fcode)) fcode = (int)p2;
       }
     }
     write_partial<NT>(mah, logp, fcode, partial_out + PARTIAL_STRIDE * (size_t)tile_index, sm.red, sm.sfail);
@@ -1110,6 +1122,8 @@ void tile_set_attributes() {
   else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     if constexpr (stage1_min_waves<T, D>() == 2) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1189,30 +1203,36 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 8, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                        Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   else {
+    // up to FOLD_GROUP * FOLD_MAX_GROUPS stage-1 workgroups: the record stages run inside the
+    // launch (fold_final), for a whole system and for one shard of a larger one alike
+    const int slot = (tiles > 1 && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
+    const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
     bool wide = false;
     if constexpr (stage1_min_waves<T, D>() == 2) {
       // at most one workgroup per CU: give each a second set of role waves for its LDS reduction
       if (tiles <= STAGE1_SMALL_TILES) {
         wide = true;
         const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
-        static_assert(Cfg::NG1 == Cfg::NTILE3 && 2 * Cfg::NT1 == Cfg::NT3, "fold_final reuses the stage-1 workgroup shape");
-        const int slot = (shard_record == nullptr && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled())
-                             ? fold_slot_for(ws) : -1;
-        if (slot >= 0) {
-          // the whole system in ONE launch: the workgroup that finishes last reduces the records
-          FoldArgs fa{slot, recB, out2, info};
+        if (slot >= 0)
           hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
                              dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, fa);
-          if (ev_stop) (void)hipEventRecord(ev_stop, st);
-          return 0;
-        }
-        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
-                           dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+        else
+          hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
+                             dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
       }
     }
-    if (!wide)
-      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                         Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+    if (!wide) {
+      if (slot >= 0)
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::NT1, true>), dim3((unsigned)tiles), dim3(Cfg::NT1),
+                           lds1, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      else
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                           Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+    }
+    if (slot >= 0) {
+      if (ev_stop) (void)hipEventRecord(ev_stop, st);
+      return 0;
+    }
   }
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
   int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;

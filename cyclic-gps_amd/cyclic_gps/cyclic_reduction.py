@@ -1,10 +1,16 @@
 """Drop-in for the reference's ``cyclic_gps/cyclic_reduction.py`` on MI355X.
 
 Same names, argument names and return structures as the reference module
-(reference file:line cited per function), but every numerical step runs in
-hand-written HIP kernels for gfx950 reached through the C ABI of
-``include/cgps.h`` (``_hip.py`` is the ctypes binding).  PyTorch only owns the
-device memory and the stream.
+(reference file:line cited per function).  The path -- ``decompose_step``,
+``decompose``, ``mahal_and_det``, ``halfsolve``, ``backhalfsolve``, ``solve``,
+``det``, ``mahal``, ``inverse_blocks`` and their gradients -- runs in hand-written
+HIP kernels for gfx950 reached through the C ABI of ``include/cgps.h``
+(``_hip.py`` is the ctypes binding); PyTorch only owns the device memory and the
+stream.  The six small banded-product helpers of the reference's surface
+(``UU_T, Ux, U_Tx, SigU, UtV_diags, interleave``, :15-200) are NOT kernels of
+this library: inside the path they are fused into the kernels above, and as
+stand-alone names they are batched torch products on whatever device their
+arguments live on.
 
 * Inputs may live on the GPU (zero-copy) or on the CPU (they are staged to the
   current GPU and results are returned on the CPU, so the reference's own

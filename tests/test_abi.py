@@ -86,21 +86,31 @@ def test_no_cpu_fallback():
         cr.decompose(Rs, Os)
 
 
-def test_helpers_match_reference_golden():
+def _check_helpers(device):
     """The banded helper products of the surface against vectors recorded from the reference."""
     import numpy as np
     for name in ("helpers_d1_n4_sq", "helpers_d1_n4_nsq", "helpers_d2_n3_sq", "helpers_d2_n3_nsq"):
         g = np.load(os.path.join(_util.GOLDEN, name + ".npz"))
-        t = torch.from_numpy
+        t = lambda a: torch.from_numpy(a).to(device)   # noqa: E731
         A, B = t(g["A"]), t(g["B"])
         dg, off = cr.UU_T(A, B)
-        np.testing.assert_allclose(dg.numpy(), g["uut_d"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(off.numpy(), g["uut_o"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(cr.Ux(A, B, t(g["x"])).numpy(), g["ux"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(cr.U_Tx(A, B, t(g["y"])).numpy(), g["utx"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(dg.cpu().numpy(), g["uut_d"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(off.cpu().numpy(), g["uut_o"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(cr.Ux(A, B, t(g["x"])).cpu().numpy(), g["ux"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(cr.U_Tx(A, B, t(g["y"])).cpu().numpy(), g["utx"], rtol=1e-12, atol=1e-12)
         mid, hi = cr.SigU(t(g["Sd"]), t(g["So"]), A, B)
-        np.testing.assert_allclose(mid.numpy(), g["su_mid"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(hi.numpy(), g["su_hi"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(cr.UtV_diags(A, B, mid, hi).numpy(), g["utv"], rtol=1e-12, atol=1e-12)
-        np.testing.assert_array_equal(cr.interleave(t(g["il_a"]), t(g["il_b"])).numpy(), g["il1"])
-        np.testing.assert_array_equal(cr.interleave(t(g["il_b"]), t(g["il_a"])).numpy(), g["il2"])
+        np.testing.assert_allclose(mid.cpu().numpy(), g["su_mid"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(hi.cpu().numpy(), g["su_hi"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(cr.UtV_diags(A, B, mid, hi).cpu().numpy(), g["utv"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(cr.interleave(t(g["il_a"]), t(g["il_b"])).cpu().numpy(), g["il1"])
+        np.testing.assert_array_equal(cr.interleave(t(g["il_b"]), t(g["il_a"])).cpu().numpy(), g["il2"])
+
+
+def test_helpers_match_reference_golden():
+    _check_helpers("cpu")
+
+
+@pytest.mark.gpu
+def test_helpers_on_device_tensors():
+    """The same six names handed device tensors (batched device products, see the module docstring)."""
+    _check_helpers("cuda")
