@@ -66,7 +66,7 @@ int cgps_finish_records(const void* records, size_t record_stride_bytes, const d
     if constexpr (!cgps::tile_supported<T, D>()) {
       return fail(CGPS_ERR_UNSUPPORTED, "sharded reduction is built for fp64 d<=5 and fp32 d<=8");
     } else {
-      if (record_stride_bytes % sizeof(T) != 0 || partial_stride_bytes % sizeof(double) != 0 ||
+      if (record_stride_bytes % 16 != 0 || partial_stride_bytes % sizeof(double) != 0 ||
           record_stride_bytes < cgps::RecordLayout<T, D>::STRIDE * sizeof(T) || partial_stride_bytes < 32)
         return fail(CGPS_ERR_ARG, "cgps_finish_records: bad record / partial stride");
       int rc = cgps::run_tile_finish<T, D>((const T*)records, (int64_t)(record_stride_bytes / sizeof(T)), partials,

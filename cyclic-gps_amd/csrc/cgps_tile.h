@@ -449,6 +449,10 @@ constexpr int FOLD_MAX_GROUPS = 64;         // <= 1024 stage-1 workgroups per la
 // [slot][0]: arrivals of the group leaders; [slot][1 + g]: arrivals of group g's workgroups
 static __device__ unsigned int g_fold_counter[FOLD_SLOTS][1 + FOLD_MAX_GROUPS];
 
+// records a record-stage lane eliminates sequentially before the LDS reduction (8 x 8 blocks: that
+// one-lane code spills; one record per lane and more workgroups instead)
+template <int D> constexpr int record_rcmax() { return D == 8 ? 1 : 4; }
+
 // A record = what a tile leaves behind: its boundary row (Rs, ys), that row's coupling
 // to the previous tile's boundary row (Cs = J[this, previous]) and the additive update
 // (dRa, dya) for the previous tile's boundary row.
@@ -671,6 +675,77 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
                                                    const double* __restrict__ partial_in, int64_t n_partial,
                                                    double* __restrict__ out2, int* __restrict__ info,
                                                    int64_t rows_per_record, int64_t N, int64_t rstride, int64_t pstride);
+// The record stages inside the launch (FOLD variants of the stage-1 kernels call this last).
+// rows_per_tile: block rows one stage-1 workgroup covers; NW: threads of the workgroup; ONE_PER_CU:
+// the launch holds at most one workgroup per CU (see COH below).
+template <typename T, int D, int NW, bool ONE_PER_CU>
+__device__ __forceinline__ void fold_record_stages(char* smem, int* last_flag, T* __restrict__ rec, double* __restrict__ partial,
+                                                   const FoldArgs& fold, int64_t rows_per_tile, int64_t N) {
+  const int tid = threadIdx.x;
+    // Two levels inside the launch.  The workgroups of a GROUP of FOLD_GROUP consecutive tiles
+    // arrive on the group's counter; the one that arrives last reduces the group's records to
+    // one (four narrow levels, ~7 KB pulled through one CU) and arrives on the launch's counter;
+    // the group leader that arrives last there reduces the group records (<= 64), and either
+    // eliminates the last row and writes out2 / info (whole system) or leaves the shard's single
+    // record and partial result (one shard of a larger system).  Against ONE workgroup taking all
+    // 256 records in a second launch: the 115 KB copy through a single CU (~3 us) becomes sixteen
+    // parallel 7 KB copies, and the two widest levels (128 and 64 eliminations, 2.3 + 1.3 us)
+    // become narrow ones (0.85 us).
+    // Hand-off (MI355X guide, inter-workgroup communication): every store of a record or
+    // partial result is a write-through store issued by wave 0; wave 0 drains them, ONE lane
+    // arrives with one returning agent-scope atomic.  With one workgroup per CU (NW = 2 NT) and a
+    // vectorised copy the last arriver reads the handed-off bytes with coherent (sc1) loads ONLY
+    // (COH: the form the guide lists as measured for exactly this shape); otherwise it takes an
+    // agent-scope acquire and uses plain loads.  The workgroup barrier holds the other waves until
+    // the arrival has returned (and the invalidate has completed).
+    constexpr bool COH = ONE_PER_CU && (D * D) % Vec16<T>::N == 0;
+    using RL = RecordLayout<T, D>;
+    const unsigned grp = blockIdx.x / FOLD_GROUP, ngrp = (gridDim.x + FOLD_GROUP - 1) / FOLD_GROUP;
+    const unsigned gsize = (grp + 1 < ngrp) ? (unsigned)FOLD_GROUP : gridDim.x - grp * FOLD_GROUP;
+    auto arrive = [&](unsigned int* ctr, unsigned expected) {
+      if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+          const bool last = atomicInc(ctr, expected - 1u) == expected - 1u;
+          *last_flag = last ? 1 : 0;
+          if (!COH && last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+      }
+      __syncthreads();
+      return *last_flag != 0;                    // workgroup-uniform
+    };
+    T* grec = reinterpret_cast<T*>(fold.group_records);
+    double* gpartial = partial + PARTIAL_STRIDE * (size_t)gridDim.x;       // the groups' partial results
+    const bool lead = arrive(&g_fold_counter[fold.slot][1 + grp], gsize);
+    CGPS_KSTAMP(4);
+    if (lead) {
+      record_reduce_body<T, D, FOLD_GROUP, NW, false, COH>(smem, grp, rec, (int64_t)gridDim.x, 1, grec, gpartial,
+                                                           (const double*)nullptr, (int64_t)0, (double*)nullptr,
+                                                           (int*)nullptr, rows_per_tile, N, (int64_t)RL::STRIDE,
+                                                           (int64_t)PARTIAL_STRIDE);
+      CGPS_KSTAMP(5);
+      const bool fin = arrive(&g_fold_counter[fold.slot][0], ngrp);
+      CGPS_KSTAMP(6);
+      if (fin) {
+        if (fold.shard_record != nullptr)
+          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, false, COH>(smem, 0u, grec, (int64_t)ngrp, 1,
+                                                                    reinterpret_cast<T*>(fold.shard_record), fold.shard_partial,
+                                                                    partial, (int64_t)gridDim.x + ngrp, (double*)nullptr,
+                                                                    (int*)nullptr, rows_per_tile * FOLD_GROUP, N,
+                                                                    (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+        else
+          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr,
+                                                                   (double*)nullptr, partial, (int64_t)gridDim.x + ngrp,
+                                                                   fold.out2, fold.info, rows_per_tile * FOLD_GROUP, N,
+                                                                   (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+        CGPS_KSTAMP(7);
+      }
+    }
+}
+
 template <typename T, int D, int C, int NT, int NW = NT, bool FOLD = false>
 __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
@@ -753,71 +828,8 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   int64_t frow = r0 < N ? r0 : N - 1;
   write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
   CGPS_KSTAMP(3);
-  if constexpr (FOLD) {
-    // Two levels inside the launch.  The workgroups of a GROUP of FOLD_GROUP consecutive tiles
-    // arrive on the group's counter; the one that arrives last reduces the group's records to
-    // one (four narrow levels, ~7 KB pulled through one CU) and arrives on the launch's counter;
-    // the group leader that arrives last there reduces the group records (<= 64), and either
-    // eliminates the last row and writes out2 / info (whole system) or leaves the shard's single
-    // record and partial result (one shard of a larger system).  Against ONE workgroup taking all
-    // 256 records in a second launch: the 115 KB copy through a single CU (~3 us) becomes sixteen
-    // parallel 7 KB copies, and the two widest levels (128 and 64 eliminations, 2.3 + 1.3 us)
-    // become narrow ones (0.85 us).
-    // Hand-off (MI355X guide, inter-workgroup communication): every store of a record or
-    // partial result is a write-through store issued by wave 0; wave 0 drains them, ONE lane
-    // arrives with one returning agent-scope atomic.  With one workgroup per CU (NW = 2 NT) and a
-    // vectorised copy the last arriver reads the handed-off bytes with coherent (sc1) loads ONLY
-    // (COH: the form the guide lists as measured for exactly this shape); otherwise it takes an
-    // agent-scope acquire and uses plain loads.  The workgroup barrier holds the other waves until
-    // the arrival has returned (and the invalidate has completed).
-    constexpr bool COH = (NW == 2 * NT) && (D * D) % Vec16<T>::N == 0;
-    using RL = RecordLayout<T, D>;
-    int* last_flag = sm.sfail + 1;
-    const unsigned grp = blockIdx.x / FOLD_GROUP, ngrp = (gridDim.x + FOLD_GROUP - 1) / FOLD_GROUP;
-    const unsigned gsize = (grp + 1 < ngrp) ? (unsigned)FOLD_GROUP : gridDim.x - grp * FOLD_GROUP;
-    auto arrive = [&](unsigned int* ctr, unsigned expected) {
-      if (tid < 64) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-          const bool last = atomicInc(ctr, expected - 1u) == expected - 1u;
-          *last_flag = last ? 1 : 0;
-          if (!COH && last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-        }
-      }
-      __syncthreads();
-      return *last_flag != 0;                    // workgroup-uniform
-    };
-    T* grec = reinterpret_cast<T*>(fold.group_records);
-    double* gpartial = partial + PARTIAL_STRIDE * (size_t)gridDim.x;       // the groups' partial results
-    const bool lead = arrive(&g_fold_counter[fold.slot][1 + grp], gsize);
-    CGPS_KSTAMP(4);
-    if (lead) {
-      record_reduce_body<T, D, FOLD_GROUP, NW, false, COH>(smem, grp, rec, (int64_t)gridDim.x, 1, grec, gpartial,
-                                                           (const double*)nullptr, (int64_t)0, (double*)nullptr,
-                                                           (int*)nullptr, (int64_t)C * NT, N, (int64_t)RL::STRIDE,
-                                                           (int64_t)PARTIAL_STRIDE);
-      CGPS_KSTAMP(5);
-      const bool fin = arrive(&g_fold_counter[fold.slot][0], ngrp);
-      CGPS_KSTAMP(6);
-      if (fin) {
-        if (fold.shard_record != nullptr)
-          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, false, COH>(smem, 0u, grec, (int64_t)ngrp, 1,
-                                                                    reinterpret_cast<T*>(fold.shard_record), fold.shard_partial,
-                                                                    partial, (int64_t)gridDim.x + ngrp, (double*)nullptr,
-                                                                    (int*)nullptr, (int64_t)C * NT * FOLD_GROUP, N,
-                                                                    (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
-        else
-          record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, grec, (int64_t)ngrp, 1, (T*)nullptr,
-                                                                   (double*)nullptr, partial, (int64_t)gridDim.x + ngrp,
-                                                                   fold.out2, fold.info, (int64_t)C * NT * FOLD_GROUP, N,
-                                                                   (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
-        CGPS_KSTAMP(7);
-      }
-    }
-  }
+  if constexpr (FOLD)
+    fold_record_stages<T, D, NW, (NW == 2 * NT)>(smem, sm.sfail + 1, rec, partial, fold, (int64_t)C * NT, N);
 }
 
 // ---- stage 3 -----------------------------------------------------------------------------
@@ -991,7 +1003,7 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
                                           mah, fail);
   }
   }
-  if constexpr (!INL) {
+  if constexpr (!INL && !(record_rcmax<D>() == 1 && (D * D) % VN == 0)) {
   if (!staged) {
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
@@ -1094,13 +1106,15 @@ template <typename T, int D> constexpr bool tile_supported() {
   return ((size_t)256 * (2 * D * D + D) + D * D) * sizeof(T) + 4096 <= 160 * 1024;
 }
 template <typename T, int D> struct TileCfg {
-  static constexpr int C = (D == 8) ? 64 : 16;   // rows per lane (per lane group) in stage 1
+  // rows per lane (per lane group) in stage 1; 8 x 8 blocks: 128 rows per group of four lanes = 8192
+  // rows per workgroup, so that 2^22 rows are 512 workgroups = ONE round of the chip (two per CU)
+  static constexpr int C = (D == 8) ? 128 : 16;
   static constexpr int NT1 = 256;      // lanes (= threads) per workgroup in stage 1
   static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
   static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
   // records a stage-3 lane eliminates sequentially before the LDS reduction (8 x 8 blocks: that
   // one-lane code spills, more workgroups with one record per lane are faster)
-  static constexpr int RCMAX = (D == 8) ? 1 : 4;
+  static constexpr int RCMAX = record_rcmax<D>();
   // lanes sharing one block row in stage 1 (cgps_tile_ml.h): 8 x 8 blocks do not fit one lane's registers
   static constexpr int LPR = (D == 8) ? 4 : 1;
   static constexpr int NG1 = NT1 / LPR;                 // kept rows (= LDS tile slots) per stage-1 workgroup
@@ -1116,9 +1130,12 @@ void tile_set_attributes() {
   if (dev < 0 || dev >= TILE_MAX_DEVICES) dev = 0;
   std::call_once(once[dev], [] {
   const int lds1 = (int)stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = (int)stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
-  if constexpr (Cfg::LPR > 1)
+  if constexpr (Cfg::LPR > 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+  }
   else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
@@ -1190,9 +1207,18 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
   tile_set_attributes<T, D>();
   if (ev_start) (void)hipEventRecord(ev_start, st);
-  if constexpr (Cfg::LPR > 1)
+  if constexpr (Cfg::LPR > 1) {
+    const int slot = (tiles > 1 && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
+    if (slot >= 0) {
+      const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
+      hipLaunchKernelGGL((chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR, true>), dim3((unsigned)tiles),
+                         dim3(Cfg::NT1), lds1, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      if (ev_stop) (void)hipEventRecord(ev_stop, st);
+      return 0;
+    }
     hipLaunchKernelGGL((chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>), dim3((unsigned)tiles), dim3(Cfg::NT1),
-                       lds1, st, Rs, Os, x, N, Oleft, recA, partial);
+                       lds1, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+  }
   else if (csel == 1)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 1, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                        Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});

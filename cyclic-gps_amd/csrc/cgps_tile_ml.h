@@ -60,11 +60,11 @@ struct MlGroup {
   }
 };
 
-template <typename T, int D, int C, int NT, int LPR>
+template <typename T, int D, int C, int NT, int LPR, bool FOLD = false>
 __global__ __launch_bounds__(NT, 2) void chunk_reduce_ml_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                                 const T* __restrict__ yg, int64_t N,
                                                                 const T* __restrict__ Oleft, T* __restrict__ rec,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial, FoldArgs fold) {
   using MG = MlGroup<T, D, LPR>;
   using LT = LdsTile<T, D>;
   using RL = RecordLayout<T, D>;
@@ -257,29 +257,10 @@ __global__ __launch_bounds__(NT, 2) void chunk_reduce_ml_kernel(const T* __restr
       sm.xch[DD + row_lo + t] = dya[t];
     }
   }
-  __syncthreads();
-  const int levels = tile_cr<T, D, NT>(sm.t, n_real, pl, mah, fail);
-  if (tid == 0) {
-    T dRl[D][D], dyl[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      dyl[i] = sm.xch[DD + i];
-#pragma unroll
-      for (int j = 0; j <= i; ++j) dRl[i][j] = sm.xch[i * D + j];
-    }
-    collect_left_updates<T, D>(sm.t, levels, dRl, dyl);
-    T Rs_[D][D], ys_[D], Cs_[D][D];
-    LT::load_blk(sm.t.R, n_real - 1, Rs_);
-    load_vec<T, D>(sm.t.y + (n_real - 1) * D, ys_);
-    LT::load_blk(sm.t.Oc, 0, Cs_);
-    T* r = rec + (size_t)blockIdx.x * RL::STRIDE;
-    store_block<T, D>(r + RL::RS, Rs_);
-    store_block<T, D>(r + RL::CS, Cs_);
-    mirror_lower<T, D>(dRl);
-    store_block<T, D>(r + RL::DRA, dRl);
-    store_vec<T, D>(r + RL::YS, ys_);
-    store_vec<T, D>(r + RL::DYA, dyl);
-  }
+  // barrier, cyclic reduction of the tile's kept rows, the record (D * D lanes, write-through stores)
+  reduce_staged_tile_and_emit<T, D, NT>(sm.t, n_real, sm.xch, rec + (size_t)blockIdx.x * RL::STRIDE, pl, mah, fail);
   int64_t frow = r0 < N ? r0 : N - 1;
   write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
+  if constexpr (FOLD)
+    fold_record_stages<T, D, NT, false>(smem, sm.sfail + 1, rec, partial, fold, (int64_t)C * NG, N);
 }

@@ -11,7 +11,7 @@ namespace cgps {
 constexpr int PARTIAL_STRIDE = 4;
 
 // TileCfg<T, d>::ROWS1 for a run-time d (workspace sizing)
-inline int64_t tile_rows1(int d) { return d == 8 ? 64 * 256 / 4 : 16 * 256; }
+inline int64_t tile_rows1(int d) { return d == 8 ? 128 * 256 / 4 : 16 * 256; }
 // Below ~2^19 rows the op is pure latency and stage 1's sequential chain of C - 1 eliminations
 // per lane is most of it.  Small systems therefore take fewer rows per lane: the smallest C of
 // {1, 4, 8, C_full} that keeps the grid within one workgroup per CU (more lanes, shorter chains,

@@ -162,7 +162,8 @@ int cgps_peg_precision_adjoint(const void* ts, const void* G, int64_t N, int d, 
  * library itself never communicates) and every rank calls cgps_finish_records, which reduces
  * the P-row boundary system and writes out2 = {mahal, logdet} and info (1 + a failing row --
  * local to the shard that saw it -- or 0).  record_stride_bytes / partial_stride_bytes are the
- * distances between consecutive shards' records / partials, so both can be read in place from
+ * distances between consecutive shards' records / partials (record stride: a multiple of 16 bytes,
+ * records 16-byte aligned), so both can be read in place from
  * the receive buffer of an all-gather of [record | partial] messages (record_out and
  * partial_out of cgps_shard_reduce may point straight into the send buffer; partial_out must
  * be 8-byte aligned).  P <= 1024 (256 for d = 8).  Built for every block size whose 256-row tile fits the LDS:
