@@ -43,6 +43,16 @@ void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts = cgps::SO
   }
 }
 
+// passes of at most one tile per CU take the "deep" kernels (CGPS_NO_DEEP_SOLVE=1: the level-by-level loads, for A/B timing)
+inline int64_t deep_tiles_max() {
+  static PerDevice<int64_t> cus;
+  return cus.get([](int dev) { return (int64_t)device_cus(dev); });
+}
+inline bool deep_solve_enabled() {
+  static const bool on = [] { const char* e = getenv("CGPS_NO_DEEP_SOLVE"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
 template <typename T, int D>
 void solve_tile_attributes() {
   static PerDevice<int> done;
@@ -52,6 +62,12 @@ void solve_tile_attributes() {
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_kernel<T, D>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if constexpr (cgps::solve_deep_supported<T, D>()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_deep_kernel<T, D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_kernel<T, D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
   return 1;
   });
 }
@@ -79,6 +95,15 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
     const int64_t nsurv = n >> P.lv[p].nlev;           // rows of the next pass
     T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D] surviving rows, then [g][D] owed vectors
     T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * D : nullptr;
+    // few tiles (at most one per CU): the latency-bound form with every factor block requested up front
+    bool deep = false;
+    if constexpr (cgps::solve_deep_supported<T, D>()) deep = g <= deep_tiles_max() && deep_solve_enabled();
+    if constexpr (cgps::solve_deep_supported<T, D>()) {
+      if (deep)
+        hipLaunchKernelGGL((cgps::halfsolve_deep_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                           P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+    }
+    if (!deep)
     hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
                        P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
     pb += g;
@@ -114,6 +139,14 @@ int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   for (int p = P.np - 1; p >= 0; --p) {
     const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
     T* X = (p == 0) ? x : bufs[p & 1];
+    bool deep = false;
+    if constexpr (cgps::solve_deep_supported<T, D>()) deep = g <= deep_tiles_max() && deep_solve_enabled();
+    if constexpr (cgps::solve_deep_supported<T, D>()) {
+      if (deep)
+        hipLaunchKernelGGL((cgps::backsolve_deep_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                           P.lv[p], ycrr, xc, n, X);
+    }
+    if (!deep)
     hipLaunchKernelGGL((cgps::backsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
                        P.lv[p], ycrr, xc, n, X);
     xc = X;

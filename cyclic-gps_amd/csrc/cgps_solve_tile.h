@@ -30,7 +30,7 @@ constexpr int SOLVE_MAXLEV = SOLVE_LP + 1;
 constexpr int SOLVE_LP_WIDE = 3;                  // levels per pass while the system is large ...
 constexpr int64_t SOLVE_WIDE_ROWS = 1 << 20;      // ... i.e. has at least this many rows (2^18 .. 2^20 measured alike)
 template <typename T, int D> constexpr size_t solve_lds_bytes() {
-  return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double) + D * sizeof(T);
+  return (size_t)SOLVE_TS * D * sizeof(T) + 2 * (SOLVE_NT / 64) * sizeof(double) + (size_t)(2 + SOLVE_MAXLEV) * D * sizeof(T);
 }
 
 // Blocks of <= 128 bytes: hold the forward sweep to 64 registers (it needs 65 otherwise), i.e. four
@@ -213,6 +213,169 @@ __global__ __launch_bounds__(SOLVE_NT, (solve_min_waves<T, D>())) void halfsolve
   }
 }
 
+
+// ---- latency-bound passes (at most one tile per CU): every factor block up front ---------------------
+// A pass over few tiles walks all levels of a tile; with the blocks of a level requested when the
+// level starts, each level exposes one HBM round trip (3.5 us measured per level: 35 us for the
+// 128-tile middle pass of N = 2^20, 12 us for the single-tile top pass).  But WHICH blocks a tile
+// needs does not depend on any data: the 512 eliminations of level 0 belong to the 512 lanes, and
+// the 512 eliminations of ALL deeper levels (256 + 128 + ... + 1 + 1) are dealt to the same 512
+// lanes, one each -- level j >= 1, elimination k to lane (512 >> j) + k, the single elimination of
+// level 10 to lane 0.  A lane requests its D / F / G of level 0 and of its deep elimination (and
+// its right-hand-side entry in the backward sweep) before anything else: ONE round trip for the
+// whole pass; after it the levels only touch LDS (two barriers each).  Six blocks in registers:
+// for blocks of at most 128 bytes (fp64 d <= 4, fp32 d <= 5), one workgroup per CU.
+template <typename T, int D> constexpr bool solve_deep_supported() { return (size_t)D * D * sizeof(T) <= 128; }
+
+struct DeepOwner {
+  int j, k;           // the deep elimination (level >= 1) this lane owns, j = -1: none
+};
+__device__ __forceinline__ DeepOwner deep_owner(int tid) {
+  DeepOwner o;
+  if (tid == 0) { o.j = SOLVE_LP; o.k = 0; return o; }
+  const int hb = 31 - __clz(tid);          // tid in [2^hb, 2^(hb+1))
+  o.j = (SOLVE_LP - 1) - hb;               // 512 >> j == 2^hb
+  o.k = tid - (1 << hb);
+  return o;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(SOLVE_NT, 2) void halfsolve_deep_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int64_t n,
+    T* __restrict__ xcrr, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* ys = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
+  double* red = reinterpret_cast<double*>(solve_smem + (size_t)SOLVE_TS * D * sizeof(T));
+  T* owed = reinterpret_cast<T*>(red + 2 * (SOLVE_NT / 64));
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * SOLVE_TS;
+  const int n0 = (int)((n - row0) < SOLVE_TS ? (n - row0) : SOLVE_TS);
+  // ---- every load of the pass --------------------------------------------------------------------
+  // level 0, elimination tid: row 2 tid, its D; the update of row 2 tid + 1 needs F and (when the
+  // right neighbour 2 tid + 2 exists) G
+  T L0[D][D], F0[D][D], G0[D][D];
+  const int ne0 = (n0 + 1) >> 1, no0 = n0 >> 1;
+  const int64_t g00 = row0 >> 1;
+  if (tid < ne0) load_block<T, D>(Dp + (lv.offD[0] + g00 + tid) * DD, L0); else set_zero_block(L0);
+  const bool upd0 = tid < no0 && lv.nlev >= 1, rgt0 = upd0 && (2 * tid + 2 < n0);
+  if (upd0) load_block<T, D>(Fp + (lv.offF[0] + g00 + tid) * DD, F0); else set_zero_block(F0);
+  if (rgt0) load_block<T, D>(Gp + (lv.offG[0] + g00 + tid) * DD, G0); else set_zero_block(G0);
+  // the lane's deep elimination (level dj >= 1 of this pass, elimination dk)
+  const DeepOwner own = deep_owner(tid);
+  const int dj = own.j, dk = own.k;
+  const int nj_d = (dj <= lv.nlev) ? (n0 >> dj) : 0;                     // rows of the tile at level dj
+  // level dj is eliminated by this pass when dj < nlev, or dj == nlev and the pass ends the system
+  // there (a single surviving row that is eliminated too: the top pass)
+  const bool elim_d = dj >= 1 && dk < ((nj_d + 1) >> 1) && (dj < lv.nlev);
+  const bool upd_d = elim_d && dk < (nj_d >> 1) && (dj + 1 <= lv.nlev) && (dj < lv.nlev);
+  const bool rgt_d = upd_d && (2 * dk + 2 < nj_d);
+  T Ld[D][D], Fd[D][D], Gd[D][D];
+  const int64_t g0d = row0 >> (dj + 1);
+  if (elim_d) load_block<T, D>(Dp + (lv.offD[dj] + g0d + dk) * DD, Ld); else set_zero_block(Ld);
+  if (upd_d) load_block<T, D>(Fp + (lv.offF[dj] + g0d + dk) * DD, Fd); else set_zero_block(Fd);
+  if (rgt_d) load_block<T, D>(Gp + (lv.offG[dj] + g0d + dk) * DD, Gd); else set_zero_block(Gd);
+  // what the tile's first elimination of every level owes the previous tile's last row: G of the
+  // block left of the tile, one level per lane (lanes 0 .. nlev - 1)
+  T Gl[D][D];
+  const bool left = tid < lv.nlev && (row0 >> (tid + 1)) >= 1 && (n0 >> tid) >= 1;
+  if (left) load_block<T, D>(Gp + (lv.offG[tid] + (row0 >> (tid + 1)) - 1) * DD, Gl); else set_zero_block(Gl);
+  // the tile's rows
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    load_vec<T, D>(y_in + (row0 + r) * D, v);
+    const int64_t wn = row0 + r + 1;
+    if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {
+      T w[D];
+      load_vec<T, D>(owed_in + (wn / spt_in) * D, w);
+#pragma unroll
+      for (int i = 0; i < D; ++i) v[i] -= w[i];
+    }
+    lds_store_vec<T, D>(ys + r * D, v);
+  }
+  __syncthreads();
+  double mah = 0.0, zero = 0.0;
+  // x = D^-1 y of elimination k of level j -> the row's slot, xcrr
+  auto eliminate = [&](int j, int k, const T (&L)[D][D]) {
+    T x[D];
+    T* slot = ys + (size_t)(((2 * k + 1) << j) - 1) * D;
+    lds_load_vec<T, D>(slot, x);
+    Chol<T, D> c;
+    chol_from_dense<T, D>(L, c);
+    fwd_subst<T, D>(c, x);
+    lds_store_vec<T, D>(slot, x);
+    store_vec<T, D>(xcrr + (lv.offD[j] + (row0 >> (j + 1)) + k) * D, x);
+#pragma unroll
+    for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+  };
+  // y'_k = y_2k+1 - F x_k - G x_k+1 of level j -> the row's slot (row k of level j + 1)
+  auto update = [&](int j, int k, bool right, const T (&F)[D][D], const T (&G)[D][D]) {
+    T x[D], yo[D];
+    T* slot = ys + (size_t)(((2 * k + 2) << j) - 1) * D;
+    lds_load_vec<T, D>(slot, yo);
+    lds_load_vec<T, D>(ys + (size_t)(((2 * k + 1) << j) - 1) * D, x);
+    gemv_sub<T, D>(yo, F, x);
+    if (right) {
+      lds_load_vec<T, D>(ys + (size_t)(((2 * k + 3) << j) - 1) * D, x);
+      gemv_sub<T, D>(yo, G, x);
+    }
+    lds_store_vec<T, D>(slot, yo);
+  };
+  if (tid < ne0) eliminate(0, tid, L0);
+  __syncthreads();
+  int nj = n0;
+  for (int j = 0; j < lv.nlev && nj >= 1; ++j) {
+    if (j == 0) { if (upd0) update(0, tid, rgt0, F0, G0); }
+    else if (dj == j && upd_d) update(j, dk, rgt_d, Fd, Gd);
+    __syncthreads();
+    if (j + 1 < lv.nlev && dj == j + 1 && elim_d) eliminate(j + 1, dk, Ld);
+    __syncthreads();
+    nj >>= 1;
+  }
+  // owed to the previous tile's last row: sum over the levels of G_left x (first elimination of the level)
+  if (left) {
+    T x[D], w[D];
+    lds_load_vec<T, D>(ys + (size_t)((1 << tid) - 1) * D, x);       // x of elimination 0 of level tid
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      T acc = T(0);
+#pragma unroll
+      for (int m2 = 0; m2 < D; ++m2) acc = fmaT(Gl[i][m2], x[m2], acc);
+      w[i] = acc;
+    }
+    lds_store_vec<T, D>(owed + (size_t)(1 + tid) * D, w);
+  }
+  __syncthreads();
+  if (y_out != nullptr) {                                // the tile's surviving rows: n0 >> nlev of them
+    const int spt_out = SOLVE_TS >> lv.nlev;
+    for (int r = tid; r < (n0 >> lv.nlev); r += SOLVE_NT) {
+      T v[D];
+      lds_load_vec<T, D>(ys + (size_t)(((r + 1) << lv.nlev) - 1) * D, v);
+      store_vec<T, D>(y_out + ((size_t)blockIdx.x * spt_out + r) * D, v);
+    }
+  }
+  if (owed_out != nullptr && tid == 0) {
+    T ow[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) ow[i] = T(0);
+    for (int l = 0; l < lv.nlev; ++l) {
+      if ((row0 >> (l + 1)) >= 1 && (n0 >> l) >= 1) {
+        T w[D];
+        lds_load_vec<T, D>(owed + (size_t)(1 + l) * D, w);
+#pragma unroll
+        for (int i = 0; i < D; ++i) ow[i] += w[i];
+      }
+    }
+    store_vec<T, D>(owed_out + (size_t)blockIdx.x * D, ow);
+  }
+  block_sum2<SOLVE_NT>(mah, zero, red);
+  if (tid == 0 && partial != nullptr) {
+    partial[2 * (size_t)blockIdx.x] = mah;
+    partial[2 * (size_t)blockIdx.x + 1] = 0.0;
+  }
+}
+
 // ---- backward sweep --------------------------------------------------------------------------
 // b      : right-hand side in CRR layout.   x_coarse : solution of this pass's surviving rows (one
 //          per full tile; level first + LP, natural order), nullptr for the top pass.
@@ -278,6 +441,99 @@ __global__ __launch_bounds__(SOLVE_NT) void backsolve_tile_kernel(
     }
     __syncthreads();
   }
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    lds_load_vec<T, D>(xs + (size_t)r * D, v);
+    store_vec<T, D>(x_out + (row0 + r) * D, v);
+  }
+}
+
+
+// backward counterpart of halfsolve_deep_kernel: same lane <-> elimination map, every block and
+// right-hand-side entry requested before the first level runs
+struct BackFlags {
+  bool on, right, left_in, left_out;
+};
+// what elimination k of level j needs: x = D^-T (b - F^T x_right - G^T x_left)
+template <typename T, int D>
+__device__ __forceinline__ BackFlags back_request(const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp,
+                                                  const T* __restrict__ b, const PassLevels& lv, int64_t row0, int n0, int j,
+                                                  int k, bool on, T (&L)[D][D], T (&F)[D][D], T (&G)[D][D], T (&r)[D]) {
+  constexpr int DD = D * D;
+  const int nj = n0 >> j;
+  const int64_t g0 = row0 >> (j + 1);
+  BackFlags f;
+  f.on = on && k < ((nj + 1) >> 1);
+  f.right = f.on && (2 * k + 1 < nj);
+  f.left_in = f.on && k >= 1;
+  f.left_out = f.on && k == 0 && g0 >= 1;                // left neighbour = previous tile's last row
+  if (f.on) {
+    load_vec<T, D>(b + (lv.offD[j] + g0 + k) * D, r);
+    load_block<T, D>(Dp + (lv.offD[j] + g0 + k) * DD, L);
+  } else {
+    set_zero_block(L);
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = T(0);
+  }
+  if (f.right) load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, F); else set_zero_block(F);
+  if (f.left_in || f.left_out) load_block<T, D>(Gp + (lv.offG[j] + g0 + k - 1) * DD, G); else set_zero_block(G);
+  return f;
+}
+template <typename T, int D>
+__device__ __forceinline__ void back_run(T* xs, int j, int k, const BackFlags& f, const T (&L)[D][D], const T (&F)[D][D],
+                                         const T (&G)[D][D], T (&r)[D], const T (&xleft)[D]) {
+  if (!f.on) return;
+  T xo[D];
+  if (f.right) {
+    lds_load_vec<T, D>(xs + (size_t)(((2 * k + 2) << j) - 1) * D, xo);
+    gemvT_sub<T, D>(r, F, xo);
+  }
+  if (f.left_in) {
+    lds_load_vec<T, D>(xs + (size_t)(((2 * k) << j) - 1) * D, xo);
+    gemvT_sub<T, D>(r, G, xo);
+  } else if (f.left_out) {
+    gemvT_sub<T, D>(r, G, xleft);
+  }
+  Chol<T, D> c;
+  chol_from_dense<T, D>(L, c);
+  bwd_subst<T, D>(c, r);
+  lds_store_vec<T, D>(xs + (size_t)(((2 * k + 1) << j) - 1) * D, r);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(SOLVE_NT, 2) void backsolve_deep_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ b, const T* __restrict__ x_coarse, int64_t n, T* __restrict__ x_out) {
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* xs = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * SOLVE_TS;
+  const int n0 = (int)((n - row0) < SOLVE_TS ? (n - row0) : SOLVE_TS);
+  T L0[D][D], F0[D][D], G0[D][D], r0[D], Ld[D][D], Fd[D][D], Gd[D][D], rd[D];
+  const BackFlags f0 = back_request<T, D>(Dp, Fp, Gp, b, lv, row0, n0, 0, tid, lv.nlev >= 1, L0, F0, G0, r0);
+  const DeepOwner own = deep_owner(tid);
+  const BackFlags fd = back_request<T, D>(Dp, Fp, Gp, b, lv, row0, n0, own.j, own.k, own.j >= 1 && own.j < lv.nlev, Ld, Fd,
+                                          Gd, rd);
+  T xleft[D];                                            // x of the previous tile's last row
+#pragma unroll
+  for (int i = 0; i < D; ++i) xleft[i] = T(0);
+  if (x_coarse != nullptr) {                             // solution of the rows that survived this pass's levels
+    const int spt = SOLVE_TS >> lv.nlev;
+    if (blockIdx.x > 0) load_vec<T, D>(x_coarse + ((size_t)blockIdx.x * spt - 1) * D, xleft);
+    for (int r = tid; r < (n0 >> lv.nlev); r += SOLVE_NT) {
+      T v[D];
+      load_vec<T, D>(x_coarse + ((size_t)blockIdx.x * spt + r) * D, v);
+      lds_store_vec<T, D>(xs + (size_t)(((r + 1) << lv.nlev) - 1) * D, v);
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = lv.nlev - 1; j >= 1; --j) {
+    if (own.j == j) back_run<T, D>(xs, j, own.k, fd, Ld, Fd, Gd, rd, xleft);
+    __syncthreads();
+  }
+  back_run<T, D>(xs, 0, tid, f0, L0, F0, G0, r0, xleft);
+  __syncthreads();
   for (int r = tid; r < n0; r += SOLVE_NT) {
     T v[D];
     lds_load_vec<T, D>(xs + (size_t)r * D, v);
