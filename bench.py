@@ -168,7 +168,7 @@ def extra_measurements(dev):
     cr.CHECK_POSITIVE_DEFINITE = False          # no device->host sync inside the timed calls
     out = {}
     for name, n, d, dtype, reps in (("opB_N2^20_d4_f64", 1 << 20, 4, torch.float64, 10),
-                                    ("c3_N2^22_d8_f32", 1 << 22, 8, torch.float32, 3),
+                                    ("c3_N2^22_d8_f32", 1 << 22, 8, torch.float32, 10),
                                     ("c4_N2^24_d4_f64_1gpu", 1 << 24, 4, torch.float64, 5)):
         try:
             Rs, Os, b, x_true, logdet_true = make_system(n, d, dtype, dev)

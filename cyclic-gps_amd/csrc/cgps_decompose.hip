@@ -115,7 +115,7 @@ int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, 
     constexpr int D = decltype(dc)::value;
     // tiled form for every block size whose 256-row tile fits the LDS (no register spills up to
     // 8x8 fp32 / 5x5 fp64); larger blocks go level by level
-    if constexpr (cgps::tile_supported<T, D>()) {
+    if constexpr (cgps::decomp_tile_supported<T, D>()) {
       if (!levelwise_solve_requested())
         return run_decompose_tile<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, ws_bytes,
                                         info, (hipStream_t)stream);

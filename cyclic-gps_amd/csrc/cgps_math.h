@@ -64,14 +64,17 @@ struct Chol {
 // sets fail when a pivot is not strictly positive (or NaN).
 template <typename T, int D>
 __device__ __forceinline__ double chol_lower(const T (&A)[D][D], Chol<T, D>& c, bool& fail) {
-  double piv = 1.0;
+  // product of the pivots: in the block's own precision while that cannot overflow (fp64 always;
+  // fp32: the float product is kept when it stays well inside the range, otherwise -- very large or
+  // very small blocks -- the product is redone in double from the factor's diagonal)
+  T piv = T(1);
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     T s = A[j][j];
 #pragma unroll
     for (int m = 0; m < j; ++m) s = fmaT(-c.l[j][m], c.l[j][m], s);
     fail = fail || !(s > T(0));
-    piv *= (double)s;
+    piv *= s;
     T r = rsqrt_fast(s);
     c.inv[j] = r;
     c.l[j][j] = s * r;
@@ -83,7 +86,15 @@ __device__ __forceinline__ double chol_lower(const T (&A)[D][D], Chol<T, D>& c, 
       c.l[i][j] = t * r;
     }
   }
-  return piv;
+  if constexpr (sizeof(T) == 4 && D > 1) {
+    if (!(piv > T(1e-30) && piv < T(1e30))) {
+      double p = 1.0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) p *= (double)c.l[j][j] * (double)c.l[j][j];
+      return p;
+    }
+  }
+  return (double)piv;
 }
 
 // v <- L^-1 v  (forward substitution).  The same routine gives a row of

@@ -451,7 +451,7 @@ static __device__ unsigned int g_fold_counter[FOLD_SLOTS][1 + FOLD_MAX_GROUPS];
 
 // records a record-stage lane eliminates sequentially before the LDS reduction (8 x 8 blocks: that
 // one-lane code spills; one record per lane and more workgroups instead)
-template <int D> constexpr int record_rcmax() { return D == 8 ? 1 : 4; }
+template <typename T, int D> constexpr int record_rcmax() { return (D == 8 || (sizeof(T) == 8 && D == 6)) ? 1 : 4; }
 
 // A record = what a tile leaves behind: its boundary row (Rs, ys), that row's coupling
 // to the previous tile's boundary row (Cs = J[this, previous]) and the additive update
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
                                           mah, fail);
   }
   }
-  if constexpr (!INL && !(record_rcmax<D>() == 1 && (D * D) % VN == 0)) {
+  if constexpr (!INL && !(record_rcmax<T, D>() == 1 && (D * D) % VN == 0)) {
   if (!staged) {
   T Rc[D][D], yc[D], Cc[D][D], dRa[D][D], dya[D];
   set_zero<T, D>(dRa);
@@ -1099,24 +1099,34 @@ static __global__ __launch_bounds__(256) void sum_partials4_kernel(const double*
 #include "cgps_tile_ml.h"
 
 // ---- host side ------------------------------------------------------------------------------
-template <typename T, int D> constexpr bool tile_supported() {
-  // every (dtype, d) whose 256-row tile fits the 160 KB of LDS: fp64 d <= 5, fp32 d <= 8.
-  // (Above fp64 d=4 / fp32 d=5 the one-lane-per-row code spills registers; it still reads the
-  // inputs once instead of three times, which is what counts for an HBM-bound path.)
+// does the 256-row LDS tile of the record stages fit the 160 KB of LDS?  (fp64 d <= 5, fp32 d <= 8)
+template <typename T, int D> constexpr bool tile_fits_256() {
   return ((size_t)256 * (2 * D * D + D) + D * D) * sizeof(T) + 4096 <= 160 * 1024;
 }
+// The fused pipeline is built for every block size 1 <= d <= 8 in both precisions.  (Above fp64
+// d=4 / fp32 d=5 the one-lane-per-row code spills registers; it still reads the inputs once
+// instead of three times, which is what counts for an HBM-bound path.)  The factor-emitting
+// decompose has its own, narrower condition: decomp_tile_supported().
+template <typename T, int D> constexpr bool tile_supported() { return D >= 1 && D <= 8; }
+template <typename T, int D> constexpr bool decomp_tile_supported() { return tile_fits_256<T, D>(); }
 template <typename T, int D> struct TileCfg {
-  // rows per lane (per lane group) in stage 1; 8 x 8 blocks: 128 rows per group of four lanes = 8192
-  // rows per workgroup, so that 2^22 rows are 512 workgroups = ONE round of the chip (two per CU)
-  static constexpr int C = (D == 8) ? 128 : 16;
-  static constexpr int NT1 = 256;      // lanes (= threads) per workgroup in stage 1
-  static constexpr int NTILE3 = 256;   // kept rows per workgroup in stage 3
+  // BIG blocks (fp64 d = 6, 7, 8): a 256-row tile does not fit the LDS; tiles of 64 / 128 kept rows
+  static constexpr bool BIG = !tile_fits_256<T, D>();
+  // lanes sharing one block row in stage 1 (cgps_tile_ml.h): 8 x 8 blocks (and 6 x 6 fp64) do not fit
+  // one lane's registers
+  static constexpr int LPR = (D == 8) ? 4 : ((BIG && D == 6) ? 2 : 1);
+  // lanes (= streaming threads) per workgroup in stage 1.  BIG blocks with one lane per row (7 x 7
+  // fp64): 128 lanes, and the workgroup always runs with 256 threads (the extra waves are role waves)
+  static constexpr int NT1 = (BIG && LPR == 1) ? 128 : 256;
+  static constexpr bool ALWAYS_WIDE = NT1 < 256;
+  // rows per lane (per lane group) in stage 1; 8 x 8 fp32 blocks: 128 rows per group of four lanes =
+  // 8192 rows per workgroup, so that 2^22 rows are 512 workgroups = ONE round of the chip (two per CU)
+  static constexpr int C = (D == 8) ? (sizeof(T) == 4 ? 128 : 64) : (LPR == 2 ? 32 : 16);
+  static constexpr int NTILE3 = BIG ? 64 : 256;   // kept rows per workgroup in stage 3
   static constexpr int NT3 = 512;      // threads per workgroup in stage 3 (extra waves = extra hands)
   // records a stage-3 lane eliminates sequentially before the LDS reduction (8 x 8 blocks: that
   // one-lane code spills, more workgroups with one record per lane are faster)
-  static constexpr int RCMAX = record_rcmax<D>();
-  // lanes sharing one block row in stage 1 (cgps_tile_ml.h): 8 x 8 blocks do not fit one lane's registers
-  static constexpr int LPR = (D == 8) ? 4 : 1;
+  static constexpr int RCMAX = record_rcmax<T, D>();
   static constexpr int NG1 = NT1 / LPR;                 // kept rows (= LDS tile slots) per stage-1 workgroup
   static constexpr int64_t ROWS1 = (int64_t)C * NG1;    // rows per stage-1 workgroup
 };
@@ -1136,7 +1146,13 @@ void tile_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   }
-  else {
+  else if constexpr (Cfg::ALWAYS_WIDE) {
+    const int ldsw = (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+  } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::NT1, true>),
@@ -1195,11 +1211,11 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   using Cfg = TileCfg<T, D>;
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
-  if (Cfg::ROWS1 != tile_rows1(D)) return -1;           // the two definitions of ROWS1 must agree
-  const int csel = (Cfg::LPR > 1) ? Cfg::C : stage1_rows_per_lane(N, Cfg::C, Cfg::NT1);
+  if (Cfg::ROWS1 != tile_rows1(D, sizeof(T))) return -1;   // the two definitions of ROWS1 must agree
+  const int csel = (Cfg::LPR > 1 || Cfg::ALWAYS_WIDE) ? Cfg::C : stage1_rows_per_lane(N, Cfg::C, Cfg::NT1);
   const int64_t rows_per_tile = (int64_t)csel * Cfg::NG1;
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
-  const int64_t tiles_cap = tile_cap(N, D);
+  const int64_t tiles_cap = tile_cap(N, D, sizeof(T));
   double* partial = reinterpret_cast<double*>(ws);
   const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
   T* recA = reinterpret_cast<T*>(ws + pbytes);
@@ -1219,7 +1235,19 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     hipLaunchKernelGGL((chunk_reduce_ml_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::LPR>), dim3((unsigned)tiles), dim3(Cfg::NT1),
                        lds1, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   }
-  else if (csel == 1)
+  else if constexpr (Cfg::ALWAYS_WIDE) {
+    const int slot = (tiles > 1 && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
+    const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+    if (slot >= 0) {
+      const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
+                         dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      if (ev_stop) (void)hipEventRecord(ev_stop, st);
+      return 0;
+    }
+    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
+                       dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+  } else if (csel == 1)
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 1, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
                        Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
   else if (csel == 4)

@@ -60,8 +60,9 @@ struct MlGroup {
   }
 };
 
+// (fp32: two workgroups per CU; fp64 blocks this large take the whole register file)
 template <typename T, int D, int C, int NT, int LPR, bool FOLD = false>
-__global__ __launch_bounds__(NT, 2) void chunk_reduce_ml_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
+__global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 2 : 1)) void chunk_reduce_ml_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                                 const T* __restrict__ yg, int64_t N,
                                                                 const T* __restrict__ Oleft, T* __restrict__ rec,
                                                                 double* __restrict__ partial, FoldArgs fold) {
@@ -129,9 +130,11 @@ __global__ __launch_bounds__(NT, 2) void chunk_reduce_ml_kernel(const T* __restr
       if (q == 0) { pl.mul(piv); fail = fail || f; }
       MG::gather_vec(yown, x);
       fwd_subst<T, D>(c, x);
-      if (q == 0) {
+      if (q == 0) {                        // one row's sum of squares in the block's precision, then into the fp64 sum
+        T sq = T(0);
 #pragma unroll
-        for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+        for (int i = 0; i < D; ++i) sq = fmaT(x[i], x[i], sq);
+        mah += (double)sq;
       }
     }
     // own rows of G = Cc^T D^-T, then dRa -= G G^T, dya -= G x

@@ -81,10 +81,10 @@ def test_ragged_sizes_against_oracle(d, dtype):
     """Every N from 1 to 70 plus sizes around the tile widths: even/odd counts at every level."""
     tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=2e-4, atol=2e-4)
     sizes = list(range(1, 71)) + [127, 128, 129, 255, 256, 257, 511, 513, 1000, 1023, 1025, 2049, 4097, 5000]
-    if d in (1, 4, 5, 8):   # tile-boundary cases of the multi-pass kernels: one-row ragged tiles at two passes
-        sizes += [65537, 66049, 131073]   # (d = 8: the four-lanes-per-row streaming kernel, 4096-row tiles)
-    if d == 8:
-        sizes += [4095, 4096, 8191, 8193, 12289]
+    if d in (1, 4, 5, 6, 7, 8):   # tile-boundary cases of the multi-pass kernels: one-row ragged tiles at two passes
+        sizes += [65537, 66049, 131073]   # (d = 8, fp64 d = 6: the several-lanes-per-row streaming kernels)
+    if d >= 6:
+        sizes += [2047, 2049, 4095, 4096, 8191, 8193, 12289, 16385]
     if d == 4:              # every rows-per-lane regime of the fused solve + log-det (1, 4, 8 rows per lane; 16: full-size tests)
         sizes += [65536, 262143, 262145, 300001, 524287]
     for n in sizes:

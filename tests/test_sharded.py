@@ -112,7 +112,8 @@ def test_collective_path_under_gloo(world, n_total, d):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float64), (4, torch.float64),
-                                     (4, torch.float32), (5, torch.float32)])
+                                     (4, torch.float32), (5, torch.float32), (5, torch.float64), (6, torch.float64),
+                                     (7, torch.float64), (8, torch.float64), (8, torch.float32)])
 @pytest.mark.parametrize("n,parts", [(7, 3), (64, 2), (300, 3), (1000, 3), (5000, 4), (16385, 2), (40000, 5)])
 def test_hip_shard_records_match_dense(d, dtype, n, parts):
     from cyclic_gps import _hip

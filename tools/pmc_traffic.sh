@@ -3,7 +3,7 @@
 # (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; on gfx950 read bytes = 2 x FETCH_SIZE).
 # usage (on the GPU box): bash tools/pmc_traffic.sh OUTDIR
 set -e
-OUT=$1
+OUT=$1; mkdir -p ${GRAFT_REPO_ROOT:-/root/repo}/$OUT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--op", default="mahal_and_det",
                     choices=["mahal_and_det", "decompose", "solve", "halfsolve", "det", "inverse_blocks"])
+    ap.add_argument("--nrhs", type=int, default=1, help="right-hand-side columns for solve / halfsolve")
     ap.add_argument("--rows", type=int, default=2 ** 20)
     ap.add_argument("--d", type=int, default=4)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -33,6 +34,8 @@ def main():
     dtype = torch.float64 if a.dtype == "f64" else torch.float32
     Rs, Os, b, _, _ = _util.conditioned_system(a.rows, a.d, dtype=dtype, device="cuda")
     dec = cr.decompose(Rs, Os) if a.op != "mahal_and_det" else None
+    if a.nrhs > 1:
+        b = (b[:, :, None] * torch.arange(1, a.nrhs + 1, dtype=b.dtype, device=b.device)).contiguous()
     fn = {
         "mahal_and_det": lambda: cr.mahal_and_det(Rs, Os, b),
         "decompose": lambda: cr.decompose(Rs, Os),
@@ -47,7 +50,8 @@ def main():
     for _ in range(a.reps):
         fn()
     torch.cuda.synchronize()
-    print("%s N=%d d=%d %s: %.1f us per call" % (a.op, a.rows, a.d, a.dtype, (time.perf_counter() - t0) / a.reps * 1e6))
+    print("%s N=%d d=%d %s nrhs=%d: %.1f us per call" % (a.op, a.rows, a.d, a.dtype, a.nrhs,
+                                                         (time.perf_counter() - t0) / a.reps * 1e6))
 
 
 if __name__ == "__main__":
