@@ -12,17 +12,30 @@ namespace {
 // ---- fused (tiled) substitution sweeps: cgps_solve_tile.h ---------------------------------------
 struct SolvePasses {
   int np;
+  int ts[8];                 // rows per tile of the pass
+  bool deep[8];              // latency-bound form (every factor block requested up front)
   int first[8];
   cgps::PassLevels lv[8];
   int64_t rows[8];
 };
 
-void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts = cgps::SOLVE_TS, int lp = cgps::SOLVE_LP) {
+// deep_tiles: passes of at most this many tiles take the latency-bound kernels (0: never): one
+// 1024-row tile when the rows fit it, 512-row tiles (twice the CUs pulling the factor) otherwise
+void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts_in = cgps::SOLVE_TS, int lp_in = cgps::SOLVE_LP,
+                 int64_t deep_tiles = 0) {
   P.np = 0;
   int lvl = 0;
   while (lvl < L.nlevels) {
     const int64_t rows = L.ms[lvl];
     const int remaining = L.nlevels - lvl;
+    int ts = ts_in, lp = lp_in;
+    bool deep = false;
+    if (deep_tiles > 0) {
+      if (rows <= ts_in) deep = true;
+      else if ((rows + ts_in / 2 - 1) / (ts_in / 2) <= deep_tiles) { deep = true; ts = ts_in / 2; lp = lp_in - 1; }
+    }
+    P.ts[P.np] = ts;
+    P.deep[P.np] = deep;
     // many tiles: a few levels per pass (every lane busy, few barrier-separated latency
     // exposures, the factor still read once); few tiles: all ten levels of a tile
     const int nl = (rows <= ts) ? remaining : (rows >= cgps::SOLVE_WIDE_ROWS ? wide_lp : lp);   // <= lp + 1
@@ -54,6 +67,12 @@ inline bool deep_solve_enabled() {
 }
 
 template <typename T, int D>
+int64_t deep_tiles_for() {
+  if constexpr (cgps::solve_deep_supported<T, D>()) return deep_solve_enabled() ? deep_tiles_max() : 0;
+  else return 0;
+}
+
+template <typename T, int D>
 void solve_tile_attributes() {
   static PerDevice<int> done;
   done.get([](int) {
@@ -63,9 +82,13 @@ void solve_tile_attributes() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_kernel<T, D>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if constexpr (cgps::solve_deep_supported<T, D>()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_deep_kernel<T, D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_deep_kernel<T, D, cgps::SOLVE_LP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_kernel<T, D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_kernel<T, D, cgps::SOLVE_LP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_deep_kernel<T, D, cgps::SOLVE_LP - 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_kernel<T, D, cgps::SOLVE_LP - 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   return 1;
@@ -80,7 +103,7 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P, cgps::SOLVE_LP_WIDE);
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, cgps::SOLVE_TS, cgps::SOLVE_LP, deep_tiles_for<T, D>());
   solve_tile_attributes<T, D>();
   double* partial = reinterpret_cast<double*>(ws + w.partial_off);
   T* bufs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
@@ -90,27 +113,33 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   int64_t n_owed = 0, pb = 0;
   int spt_in = 1;
   for (int p = 0; p < P.np; ++p) {
-    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    const int64_t n = P.rows[p], g = (n + P.ts[p] - 1) / P.ts[p];
     const bool more = (p + 1 < P.np);
     const int64_t nsurv = n >> P.lv[p].nlev;           // rows of the next pass
     T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D] surviving rows, then [g][D] owed vectors
     T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * D : nullptr;
-    // few tiles (at most one per CU): the latency-bound form with every factor block requested up front
-    bool deep = false;
-    if constexpr (cgps::solve_deep_supported<T, D>()) deep = g <= deep_tiles_max() && deep_solve_enabled();
+    bool launched = false;
     if constexpr (cgps::solve_deep_supported<T, D>()) {
-      if (deep)
-        hipLaunchKernelGGL((cgps::halfsolve_deep_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
-                           P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+      // few tiles (at most one per CU): the latency-bound form with every factor block requested up front
+      if (P.deep[p] && P.ts[p] == cgps::SOLVE_TS) {
+        hipLaunchKernelGGL((cgps::halfsolve_deep_kernel<T, D, cgps::SOLVE_LP>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st,
+                           Dp, Fp, Gp, P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+        launched = true;
+      } else if (P.deep[p]) {
+        hipLaunchKernelGGL((cgps::halfsolve_deep_kernel<T, D, cgps::SOLVE_LP - 1>), dim3((unsigned)g),
+                           dim3(cgps::SOLVE_NT / 2), lds, st, Dp, Fp, Gp, P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout,
+                           owed_out, partial + 2 * pb);
+        launched = true;
+      }
     }
-    if (!deep)
-    hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
-                       P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
+    if (!launched)
+      hipLaunchKernelGGL((cgps::halfsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                         P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
     pb += g;
     y = yout;
     owed_in = owed_out;
     n_owed = g;
-    spt_in = cgps::SOLVE_TS >> P.lv[p].nlev;
+    spt_in = P.ts[p] >> P.lv[p].nlev;
     if (spt_in < 1) spt_in = 1;
   }
   if (mahal_out) {
@@ -130,25 +159,30 @@ int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P, cgps::SOLVE_LP_WIDE);      // (the two sweeps need not use the same passes; 3 / 3 measured best)
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, cgps::SOLVE_TS, cgps::SOLVE_LP, deep_tiles_for<T, D>());   // (same passes as the forward sweep)
   solve_tile_attributes<T, D>();
   T* bufs[2] = {reinterpret_cast<T*>(ws + w.partial_bytes),
                 reinterpret_cast<T*>(ws + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA))};
   const size_t lds = cgps::solve_lds_bytes<T, D>();
   const T* xc = nullptr;
   for (int p = P.np - 1; p >= 0; --p) {
-    const int64_t n = P.rows[p], g = (n + cgps::SOLVE_TS - 1) / cgps::SOLVE_TS;
+    const int64_t n = P.rows[p], g = (n + P.ts[p] - 1) / P.ts[p];
     T* X = (p == 0) ? x : bufs[p & 1];
-    bool deep = false;
-    if constexpr (cgps::solve_deep_supported<T, D>()) deep = g <= deep_tiles_max() && deep_solve_enabled();
+    bool launched = false;
     if constexpr (cgps::solve_deep_supported<T, D>()) {
-      if (deep)
-        hipLaunchKernelGGL((cgps::backsolve_deep_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
-                           P.lv[p], ycrr, xc, n, X);
+      if (P.deep[p] && P.ts[p] == cgps::SOLVE_TS) {
+        hipLaunchKernelGGL((cgps::backsolve_deep_kernel<T, D, cgps::SOLVE_LP>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st,
+                           Dp, Fp, Gp, P.lv[p], ycrr, xc, n, X);
+        launched = true;
+      } else if (P.deep[p]) {
+        hipLaunchKernelGGL((cgps::backsolve_deep_kernel<T, D, cgps::SOLVE_LP - 1>), dim3((unsigned)g),
+                           dim3(cgps::SOLVE_NT / 2), lds, st, Dp, Fp, Gp, P.lv[p], ycrr, xc, n, X);
+        launched = true;
+      }
     }
-    if (!deep)
-    hipLaunchKernelGGL((cgps::backsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
-                       P.lv[p], ycrr, xc, n, X);
+    if (!launched)
+      hipLaunchKernelGGL((cgps::backsolve_tile_kernel<T, D>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                         P.lv[p], ycrr, xc, n, X);
     xc = X;
   }
   return check_launch("backsolve (tiled)");

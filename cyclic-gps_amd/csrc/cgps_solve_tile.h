@@ -221,7 +221,7 @@ __global__ __launch_bounds__(SOLVE_NT, (solve_min_waves<T, D>())) void halfsolve
 // needs does not depend on any data: the 512 eliminations of level 0 belong to the 512 lanes, and
 // the 512 eliminations of ALL deeper levels (256 + 128 + ... + 1 + 1) are dealt to the same 512
 // lanes, one each -- level j >= 1, elimination k to lane (512 >> j) + k, the single elimination of
-// level 10 to lane 0.  A lane requests its D / F / G of level 0 and of its deep elimination (and
+// level 10 to lane 0 (1024-row tiles; 512-row tiles, TSL = 9, likewise with 256 lanes).  A lane requests its D / F / G of level 0 and of its deep elimination (and
 // its right-hand-side entry in the backward sweep) before anything else: ONE round trip for the
 // whole pass; after it the levels only touch LDS (two barriers each).  Six blocks in registers:
 // for blocks of at most 128 bytes (fp64 d <= 4, fp32 d <= 5), one workgroup per CU.
@@ -230,21 +230,22 @@ template <typename T, int D> constexpr bool solve_deep_supported() { return (siz
 struct DeepOwner {
   int j, k;           // the deep elimination (level >= 1) this lane owns, j = -1: none
 };
+template <int TSL>
 __device__ __forceinline__ DeepOwner deep_owner(int tid) {
   DeepOwner o;
-  if (tid == 0) { o.j = SOLVE_LP; o.k = 0; return o; }
+  if (tid == 0) { o.j = TSL; o.k = 0; return o; }
   const int hb = 31 - __clz(tid);          // tid in [2^hb, 2^(hb+1))
-  o.j = (SOLVE_LP - 1) - hb;               // 512 >> j == 2^hb
+  o.j = (TSL - 1) - hb;                    // (TS / 2) >> j == 2^hb
   o.k = tid - (1 << hb);
   return o;
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(SOLVE_NT, 2) void halfsolve_deep_kernel(
+template <typename T, int D, int TSL>
+__global__ __launch_bounds__((1 << TSL) / 2, 2) void halfsolve_deep_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
     const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int64_t n,
     T* __restrict__ xcrr, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
-  constexpr int DD = D * D;
+  constexpr int DD = D * D, SOLVE_TS = 1 << TSL, SOLVE_NT = SOLVE_TS / 2;     // (shadow the single-column constants)
   extern __shared__ __attribute__((aligned(16))) char solve_smem[];
   T* ys = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
   double* red = reinterpret_cast<double*>(solve_smem + (size_t)SOLVE_TS * D * sizeof(T));
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(SOLVE_NT, 2) void halfsolve_deep_kernel(
   if (upd0) load_block<T, D>(Fp + (lv.offF[0] + g00 + tid) * DD, F0); else set_zero_block(F0);
   if (rgt0) load_block<T, D>(Gp + (lv.offG[0] + g00 + tid) * DD, G0); else set_zero_block(G0);
   // the lane's deep elimination (level dj >= 1 of this pass, elimination dk)
-  const DeepOwner own = deep_owner(tid);
+  const DeepOwner own = deep_owner<TSL>(tid);
   const int dj = own.j, dk = own.k;
   const int nj_d = (dj <= lv.nlev) ? (n0 >> dj) : 0;                     // rows of the tile at level dj
   // level dj is eliminated by this pass when dj < nlev, or dj == nlev and the pass ends the system
@@ -500,10 +501,11 @@ __device__ __forceinline__ void back_run(T* xs, int j, int k, const BackFlags& f
   lds_store_vec<T, D>(xs + (size_t)(((2 * k + 1) << j) - 1) * D, r);
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(SOLVE_NT, 2) void backsolve_deep_kernel(
+template <typename T, int D, int TSL>
+__global__ __launch_bounds__((1 << TSL) / 2, 2) void backsolve_deep_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
     const T* __restrict__ b, const T* __restrict__ x_coarse, int64_t n, T* __restrict__ x_out) {
+  constexpr int SOLVE_TS = 1 << TSL, SOLVE_NT = SOLVE_TS / 2;                 // (shadow the single-column constants)
   extern __shared__ __attribute__((aligned(16))) char solve_smem[];
   T* xs = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
   const int tid = threadIdx.x;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(SOLVE_NT, 2) void backsolve_deep_kernel(
   const int n0 = (int)((n - row0) < SOLVE_TS ? (n - row0) : SOLVE_TS);
   T L0[D][D], F0[D][D], G0[D][D], r0[D], Ld[D][D], Fd[D][D], Gd[D][D], rd[D];
   const BackFlags f0 = back_request<T, D>(Dp, Fp, Gp, b, lv, row0, n0, 0, tid, lv.nlev >= 1, L0, F0, G0, r0);
-  const DeepOwner own = deep_owner(tid);
+  const DeepOwner own = deep_owner<TSL>(tid);
   const BackFlags fd = back_request<T, D>(Dp, Fp, Gp, b, lv, row0, n0, own.j, own.k, own.j >= 1 && own.j < lv.nlev, Ld, Fd,
                                           Gd, rd);
   T xleft[D];                                            // x of the previous tile's last row
