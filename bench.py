@@ -43,8 +43,8 @@ for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests"
 HBM_PEAK_GBPS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:36
 ROWS_PER_GPU = 1 << 20         # config 2 (and the weak-scaling point)
 ROWS_CONFIG4 = 1 << 24         # config 4: ONE system, sharded over the GPUs
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"
-KERNEL_STATS_FILE = "r01_kernel_stats_headline_v9.csv"
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
+KERNEL_STATS_FILE = "r02_kernel_stats_headline.csv"
 D = 4
 DTYPE = torch.float64
 
