@@ -1,6 +1,6 @@
 // Fused solve + log-det (mahal_and_det, reference cyclic_reduction.py:380-438):
-// the whole reduction in two launches (three and more only for N > 2^20 rows),
-// every input byte read from HBM exactly once.
+// the whole reduction in ONE launch up to 2^22 rows (record launches only beyond 1024 stage-1
+// workgroups), every input byte read from HBM exactly once.
 //
 // x^T J^-1 x and log|J| do not depend on the elimination order, so this path
 // orders the block Gaussian elimination for the hardware (the factor-emitting
@@ -23,10 +23,12 @@
 //    of the new coupling block): the operands are in LDS anyway, no shuffles.
 //    Levels with few eliminations (4 x 4 fp64 blocks) run on the matrix cores
 //    instead, sixteen lanes per elimination: cgps_tile_mfma.h.
-//  stage 3, record_reduce_kernel: records are rows of a (N / (C NT))-row system;
-//    the same tile_cr reduces them (recursively for very large N) and the last
-//    launch eliminates the final row, sums the partial log-det / mahal in a
-//    fixed order and writes the info word.
+//  record stages: records are rows of a (N / (C NT))-row system.  Inside the stage-1 launch
+//    (fold_record_stages): the workgroup of a group of 16 tiles that arrives last reduces the
+//    group's records with the same tile_cr, the group leader that arrives last reduces the
+//    group records, eliminates the final row, sums the partial log-det / mahal in a fixed order
+//    and writes the info word (or leaves a shard's single record).  Beyond 1024 stage-1
+//    workgroups: record_reduce_kernel launches (recursively for very large N).
 //
 // Ragged sizes are exact, no padding rows: a short chunk / tile simply keeps its
 // last REAL row, which is what lets a shard of a larger system (one per GPU) be
