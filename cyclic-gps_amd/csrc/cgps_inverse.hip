@@ -8,6 +8,9 @@
 using namespace cgps_host;
 
 namespace {
+#ifndef CGPS_INV_FUSED_MAX_BLOCK
+#define CGPS_INV_FUSED_MAX_BLOCK 200
+#endif
 constexpr int64_t INV_FUSED_MIN_ROWS = 1024;   // a fused inverse pass must produce at least this many rows
 template <typename T, int D>
 int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, char* ws, size_t ws_bytes,
@@ -23,7 +26,7 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   // multiple of INV_LP above level 0 is reached and the rows get many, INV_LP levels per launch
   // (cgps_inverse_tile.h): those passes read 1/8 of what they write instead of ping-ponging every
   // level's Sigma through HBM.
-  constexpr bool FUSED = (size_t)D * D * sizeof(T) <= 128;
+  constexpr bool FUSED = (size_t)D * D * sizeof(T) <= (size_t)CGPS_INV_FUSED_MAX_BLOCK;
   const size_t lds = (size_t)64 * D * D * sizeof(T);
   static PerDevice<int> grid_caps;                    // persistent waves: what this device holds at once
   const int grid_cap = !FUSED ? 1 : grid_caps.get([&](int dev) {
