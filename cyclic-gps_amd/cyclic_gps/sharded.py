@@ -100,6 +100,92 @@ class ShardedMahalLogdet:
         return out
 
 
+def boundary_system(recv, world, rec_bytes, msg_bytes, d, dtype):
+    """The world-row block-tridiagonal system of the shards' LAST rows, from the gathered records
+    (layout: RecordLayout in csrc/cgps_tile.h: Rs | Cs | dRa | ys | dya):
+        R_w = Rs_w + dRa_{w+1},   y_w = ys_w + dya_{w+1},   O_w = Cs_{w+1}  (= J[w+1, w] after the
+    shards' interiors have been eliminated).  cgps_finish_records reduces it for {mahal, logdet};
+    the sharded solve needs its solution."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    n_rec = rec_bytes // esz
+    msgs = recv.view(world, msg_bytes)[:, :rec_bytes].contiguous().view(dtype).view(world, n_rec)
+    dd = d * d
+    Rb = msgs[:, 0:dd].reshape(world, d, d).clone()
+    Cs = msgs[:, dd:2 * dd].reshape(world, d, d)
+    dRa = msgs[:, 2 * dd:3 * dd].reshape(world, d, d)
+    yb = msgs[:, 3 * dd:3 * dd + d].clone()
+    dya = msgs[:, 3 * dd + d:3 * dd + 2 * d]
+    Rb[:-1] += dRa[1:]
+    yb[:-1] += dya[1:]
+    Rb = 0.5 * (Rb + Rb.transpose(-1, -2))        # (the records hold symmetric blocks up to rounding)
+    return Rb.contiguous(), Cs[1:].contiguous(), yb.contiguous()
+
+
+class HipSolveOps:
+    """Block-tridiagonal solves of the sharded solve through the drop-in module (the HIP kernels)."""
+
+    @staticmethod
+    def factor(Rs, Os):
+        from . import cyclic_reduction as cr
+        return cr.decompose(Rs, Os)
+
+    @staticmethod
+    def solve(dec, y):
+        from . import cyclic_reduction as cr
+        return cr.solve(dec, y)
+
+
+class ShardedSolve:
+    """x = J^-1 y for ONE block-tridiagonal system whose rows are split over the ranks (the posterior
+    mean of a system too large for one GPU; the reference has nothing like it).
+
+    Domain decomposition over the shards' last rows (the separators), with the same record as the
+    sharded mahal_and_det:
+      1. every rank reduces its shard WITH the right-hand side to one record (cgps_shard_reduce:
+         the Schur complement of its interior on its own last row and on the previous shard's);
+      2. ONE all-gather of the records; every rank solves the world-row boundary system
+         (boundary_system) and so knows x at every separator;
+      3. every rank solves its interior rows (all but its last one) with the two separator values
+         moved to the right-hand side -- a local decompose + solve, no further communication.
+    The interior factor is kept between calls (Rs / Os are fixed, y changes).  `ops` / `solve_ops`
+    are the device steps (defaults: the HIP library); tests inject CPU stand-ins under gloo."""
+
+    def __init__(self, Rs, Os, O_left, n_total, rank, world, group=None, ops=None, solve_ops=None):
+        self.Rs, self.Os, self.O_left = Rs, Os, O_left
+        self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
+        self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
+        self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
+        self.solve_ops = solve_ops if solve_ops is not None else HipSolveOps
+        self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
+        dev = Rs.device
+        self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(world * self.msg_bytes, dtype=torch.uint8, device=dev)
+        self._interior = None
+
+    def run(self, y):
+        n, d = self.n_loc, self.d
+        y = y.contiguous()
+        self.ops.shard_reduce(self.Rs, self.Os, y, self.O_left, self.send, self.rec_bytes)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)      # the ONE collective
+            src = self.recv
+        else:
+            src = self.send
+        Rb, Ob, yb = boundary_system(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype)
+        x_sep = self.solve_ops.solve(self.solve_ops.factor(Rb, Ob), yb)              # [world, d], same on every rank
+        x = torch.empty_like(y)
+        x[-1] = x_sep[self.rank]
+        if n > 1:
+            rhs = y[:-1].clone()
+            if self.rank > 0:
+                rhs[0] -= self.O_left @ x_sep[self.rank - 1]
+            rhs[-1] -= self.Os[n - 2].T @ x_sep[self.rank]
+            if self._interior is None:
+                self._interior = self.solve_ops.factor(self.Rs[:-1].contiguous(), self.Os[:n - 2].contiguous())
+            x[:-1] = self.solve_ops.solve(self._interior, rhs)
+        return x
+
+
 def make_sharded_system(n_total, d, dtype, device, rank, world, group=None, seed=1234):
     """This rank's shard of the conditioned bidiagonal-factor system of SURVEY.md 8(d)
     (J = L L^T, L block lower bidiagonal: closed-form log-det and planted solution), generated
@@ -139,6 +225,7 @@ def make_sharded_system(n_total, d, dtype, device, rank, world, group=None, seed
     if world > 1:
         dist.all_reduce(local, group=group)
     O_left = None if O_left is None else O_left.to(dtype).contiguous()
+    make_sharded_system.last_x_true = xt.to(dtype)          # this rank's rows of the planted solution (for ShardedSolve checks)
     return (Rs.to(dtype).contiguous(), Os_all[:-1].to(dtype).contiguous(), b.to(dtype).contiguous(), O_left,
             float(local[0]), float(local[1]))
 

@@ -105,3 +105,15 @@ class DenseShardOps:
         partials = [msgs[r, n_rec:n_rec + 4] for r in range(world)]
         m, ld = dense_finish(records, partials, self.d)
         out[0], out[1] = float(m), float(ld)
+
+
+class OracleSolveOps:
+    """Drop-in for cyclic_gps.sharded.HipSolveOps on CPU tensors: the oracle's decompose / solve."""
+
+    @staticmethod
+    def factor(Rs, Os):
+        return O.decompose(Rs, Os)
+
+    @staticmethod
+    def solve(dec, y):
+        return O.solve(dec, y)

@@ -184,3 +184,81 @@ def test_config4_as_eight_shards_on_one_gpu():
     np.testing.assert_allclose(got, [mahal_true, logdet], rtol=1e-10)
     m, ld = cr.mahal_and_det(Rs, Os, b)                     # the same system as ONE shard
     np.testing.assert_allclose(got, [float(m), float(ld)], rtol=1e-12)
+
+
+# ---- sharded solve (ShardedSolve: records -> separator values -> local interior solves) -------------------
+def _gloo_solve_worker(rank, world, port, n_total, d, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Rs, Os, b, O_left, _, _ = sharded.make_sharded_system(n_total, d, torch.float64, torch.device("cpu"), rank, world)
+        x_true = sharded.make_sharded_system.last_x_true
+        plan = sharded.ShardedSolve(Rs, Os, O_left, n_total, rank, world, ops=SD.DenseShardOps(d), solve_ops=SD.OracleSolveOps)
+        x = plan.run(b)
+        err = float((x - x_true).abs().max())
+        x2 = plan.run(2.0 * b)                       # the interior factor is reused; the solve is linear
+        err2 = float((x2 - 2.0 * x_true).abs().max())
+        errs = [None] * world
+        dist.all_gather_object(errs, (err, err2))
+        if rank == 0:
+            q.put(errs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,d", [(2, 257, 3), (3, 100, 2), (2, 3, 4), (3, 3, 2)])
+def test_sharded_solve_under_gloo(world, n_total, d):
+    """x = J^-1 y of a system split over ranks (shards of one row included) against the planted solution."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_gloo_solve_worker, args=(world, _free_port(), n_total, d, q), nprocs=world, join=True)
+    for err, err2 in q.get():
+        assert err < 1e-9 and err2 < 1e-9, (err, err2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,parts,dtype", [(5000, 4, 4, torch.float64), (70001, 3, 5, torch.float64),
+                                             (2 ** 20, 4, 8, torch.float64), (40000, 8, 3, torch.float32)])
+def test_sharded_solve_on_one_gpu(n, d, parts, dtype):
+    """The same three steps with the HIP kernels, the ranks played one after the other on one GPU:
+    shard records (cgps_shard_reduce with the right-hand side) -> boundary system -> separator values
+    -> every shard's interior through decompose + solve; against the planted solution."""
+    import cyclic_gps.cyclic_reduction as cr
+    dev = torch.device("cuda")
+    Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=3 + n)
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    rec_bytes, msg_bytes = sharded.message_layout(d, dtype)
+    recv = torch.zeros(parts * msg_bytes, dtype=torch.uint8, device=dev)
+    shards = _split(Rs, Os, b, bounds)
+    for r, (sR, sO, sx, Ol) in enumerate(shards):
+        ops = sharded.HipShardOps(sR.shape[0], d, dtype, dev)
+        ops.shard_reduce(sR.contiguous(), sO.contiguous(), sx.contiguous(), None if Ol is None else Ol.contiguous(),
+                         recv[r * msg_bytes:(r + 1) * msg_bytes], rec_bytes)
+    Rb, Ob, yb = sharded.boundary_system(recv, parts, rec_bytes, msg_bytes, d, dtype)
+    x_sep = cr.solve(cr.decompose(Rb, Ob), yb)
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    for r, (sR, sO, sx, Ol) in enumerate(shards):
+        plan = sharded.ShardedSolve(sR.contiguous(), sO.contiguous(), None if Ol is None else Ol.contiguous(), n, r, 1)
+        # world = 1 inside the plan would rebuild a one-row boundary system: drive step 3 directly instead
+        nl = sR.shape[0]
+        x = torch.empty_like(sx)
+        x[-1] = x_sep[r]
+        if nl > 1:
+            rhs = sx[:-1].clone()
+            if r > 0:
+                rhs[0] -= Ol @ x_sep[r - 1]
+            rhs[-1] -= sO[nl - 2].T @ x_sep[r]
+            x[:-1] = cr.solve(cr.decompose(sR[:-1].contiguous(), sO[:nl - 2].contiguous()), rhs)
+        lo, hi = bounds[r]
+        assert float((x - x_true[lo:hi]).abs().max()) <= tol, (r, float((x - x_true[lo:hi]).abs().max()))
+        del plan
+
+
+@pytest.mark.gpu
+def test_sharded_solve_plan_world1_on_gpu():
+    n, d = 30000, 4
+    Rs, Os, b, O_left, _, _ = sharded.make_sharded_system(n, d, torch.float64, torch.device("cuda"), 0, 1)
+    x_true = sharded.make_sharded_system.last_x_true
+    plan = sharded.ShardedSolve(Rs, Os, O_left, n, 0, 1)
+    assert float((plan.run(b) - x_true).abs().max()) < 1e-9
+    assert float((plan.run(3 * b) - 3 * x_true).abs().max()) < 1e-9
