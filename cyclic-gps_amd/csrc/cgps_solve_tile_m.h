@@ -40,6 +40,53 @@ struct Panel {
       for (int c = 0; c < MC; ++c)
         if (c < w) p[(size_t)i * ld + c] = v[i][c];
   }
+  // global, dense [d][MC] (ld == MC, every column real): 16-byte vectors when a panel row is a
+  // whole number of them (then every row is 16-byte aligned too), contiguous scalars otherwise
+  static constexpr bool VEC = (D * MC) % Vec16<T>::N == 0;
+  __device__ __forceinline__ void load_dense(const T* __restrict__ p) {
+    T* flat = &v[0][0];
+    if constexpr (VEC) {
+      constexpr int VN = Vec16<T>::N;
+      using V = typename Vec16<T>::type;
+      const V* q = reinterpret_cast<const V*>(p);
+#pragma unroll
+      for (int g = 0; g < D * MC / VN; ++g) {
+        const V x = q[g];
+        const T* e = reinterpret_cast<const T*>(&x);
+#pragma unroll
+        for (int u = 0; u < VN; ++u) flat[g * VN + u] = e[u];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D * MC; ++i) flat[i] = p[i];
+    }
+  }
+  __device__ __forceinline__ void store_dense(T* __restrict__ p) const {
+    const T* flat = &v[0][0];
+    if constexpr (VEC) {
+      constexpr int VN = Vec16<T>::N;
+      using V = typename Vec16<T>::type;
+      V* q = reinterpret_cast<V*>(p);
+#pragma unroll
+      for (int g = 0; g < D * MC / VN; ++g) {
+        V x;
+        T* e = reinterpret_cast<T*>(&x);
+#pragma unroll
+        for (int u = 0; u < VN; ++u) e[u] = flat[g * VN + u];
+        q[g] = x;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D * MC; ++i) p[i] = flat[i];
+    }
+  }
+  // either form, chosen per call (wave-uniform)
+  __device__ __forceinline__ void load_any(const T* __restrict__ p, int ld, int w) {
+    if (ld == MC && w == MC) load_dense(p); else load(p, ld, w);
+  }
+  __device__ __forceinline__ void store_any(T* __restrict__ p, int ld, int w) const {
+    if (ld == MC && w == MC) store_dense(p); else store(p, ld, w);
+  }
   // LDS, dense [d][MC]
   __device__ __forceinline__ void lds_load(const T* p) {
 #pragma unroll
@@ -151,11 +198,11 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
   const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
   for (int r = tid; r < n0; r += NT) {
     P v;
-    v.load(y_in + (row0 + r) * (size_t)D * ld_y, ld_y, w);
+    v.load_any(y_in + (row0 + r) * (size_t)D * ld_y, ld_y, w);
     const int64_t wn = row0 + r + 1;
     if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {     // the last survivor of a tile of the previous pass
       P o;
-      o.load(owed_in + (wn / spt_in) * (size_t)PW, MC, MC);
+      o.load_dense(owed_in + (wn / spt_in) * (size_t)PW);
       v.sub(o);
     }
     v.lds_store(ys + (size_t)r * PW);
@@ -172,7 +219,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
     chol_from_dense<T, D>(L, c);
     x.fwd(c);
     x.lds_store(ys + (size_t)(((2 * k + 1) << j) - 1) * PW);
-    x.store(xcrr + (lv.offD[j] + g0 + k) * (size_t)D * ld_x, ld_x, w);
+    x.store_any(xcrr + (lv.offD[j] + g0 + k) * (size_t)D * ld_x, ld_x, w);
     mah += x.sumsq();
     if (k == 0 && g0 >= 1) {                             // the previous tile's last row is this row's left neighbour
       T G[D][D];
@@ -217,7 +264,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
     for (int r = tid; r < nj; r += NT) {
       P v;
       v.lds_load(ys + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
-      v.store(y_out + ((size_t)blockIdx.x * spt_out + r) * PW, MC, MC);
+      v.store_dense(y_out + ((size_t)blockIdx.x * spt_out + r) * PW);
     }
   }
   if (owed_out != nullptr)
@@ -246,10 +293,10 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_
   xleft.zero();
   if (x_coarse != nullptr) {                             // solution of the rows that survived this pass's levels
     const int spt = TS >> lv.nlev;
-    if (blockIdx.x > 0) xleft.load(x_coarse + ((size_t)blockIdx.x * spt - 1) * PW, MC, MC);
+    if (blockIdx.x > 0) xleft.load_dense(x_coarse + ((size_t)blockIdx.x * spt - 1) * PW);
     for (int r = tid; r < (n0 >> lv.nlev); r += NT) {
       P v;
-      v.load(x_coarse + ((size_t)blockIdx.x * spt + r) * PW, MC, MC);
+      v.load_dense(x_coarse + ((size_t)blockIdx.x * spt + r) * PW);
       v.lds_store(xs + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
     }
   }
@@ -263,7 +310,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_
       for (int k = tid; k < ne; k += NT) {
         T M[D][D];
         P r, xo;
-        r.load(b + (lv.offD[j] + g0 + k) * (size_t)D * ld_b, ld_b, w);
+        r.load_any(b + (lv.offD[j] + g0 + k) * (size_t)D * ld_b, ld_b, w);
         if (2 * k + 1 < nj) {
           load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
           xo.lds_load(xs + (size_t)(((2 * k + 2) << j) - 1) * PW);
@@ -290,7 +337,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_
   for (int r = tid; r < n0; r += NT) {
     P v;
     v.lds_load(xs + (size_t)r * PW);
-    v.store(x_out + (row0 + r) * (size_t)D * ld_o, ld_o, w);
+    v.store_any(x_out + (row0 + r) * (size_t)D * ld_o, ld_o, w);
   }
 }
 
