@@ -11,6 +11,10 @@ namespace {
 #ifndef CGPS_INV_FUSED_MAX_BLOCK
 #define CGPS_INV_FUSED_MAX_BLOCK 200
 #endif
+inline bool inverse_deep_enabled() {        // CGPS_NO_DEEP_INVERSE=1: one launch per coarse level (A/B timing)
+  static const bool on = [] { const char* e = getenv("CGPS_NO_DEEP_INVERSE"); return !(e && e[0] == '1'); }();
+  return on;
+}
 constexpr int64_t INV_FUSED_MIN_ROWS = 1024;   // a fused inverse pass must produce at least this many rows
 template <typename T, int D>
 int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, char* ws, size_t ws_bytes,
@@ -35,7 +39,43 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
     return device_cus(dev) * (nb > 0 ? nb : 1);
   });
   int p = 0;
-  for (int l = L.nlevels - 1; l >= 0;) {
+  int l_start = L.nlevels - 1;
+  if constexpr (cgps::inverse_deep_supported<T, D>()) {
+    // the coarse end in ONE launch (inverse_deep_kernel): from the single row of the coarsest level down
+    // to the finest level of at most INVD_TS rows at which the three-levels-per-launch passes can take
+    // over (a multiple of INV_LP), or to level 0 of a small system
+    if (inverse_deep_enabled()) {
+      constexpr int INVD_TS_ = 1 << cgps::invd_tsl<T, D>();
+      int lf = -1;
+      for (int l = 0; l < L.nlevels; ++l)
+        if (L.ms[l] <= INVD_TS_ && (l % cgps::INV_LP == 0 || !FUSED)) { lf = l; break; }
+      if (lf < 0)
+        for (int l = 0; l < L.nlevels; ++l)
+          if (L.ms[l] <= INVD_TS_) { lf = l; break; }
+      if (lf >= 0 && L.nlevels - lf <= cgps::INVD_MAXLEV) {
+        static PerDevice<int> attr;
+        attr.get([](int) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::inverse_deep_kernel<T, D>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cgps::inverse_deep_lds_bytes<T, D>());
+          return 1;
+        });
+        cgps::InverseDeepLevels dl;
+        dl.nlev = L.nlevels - lf;
+        for (int j = 0; j < cgps::INVD_MAXLEV; ++j) {
+          const int l = lf + j < L.nlevels ? lf + j : L.nlevels - 1;
+          dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+        }
+        T* od = (lf == 0) ? Sd : bufs[p];
+        T* oo = (lf == 0) ? So : bufs[p] + cap * D * D;
+        const size_t lds_deep = cgps::inverse_deep_lds_bytes<T, D>();
+        hipLaunchKernelGGL((cgps::inverse_deep_kernel<T, D>), dim3(1), dim3(INVD_TS_ / 2), lds_deep, st, Dp, Fp, Gp, dl,
+                           (int)L.ms[lf], od, oo);
+        Sdc = od; Soc = oo; p ^= 1;
+        l_start = lf - 1;
+      }
+    }
+  }
+  for (int l = l_start; l >= 0;) {
     const int have = l + 1;                               // Sdc / Soc hold Sigma of this level
     if (FUSED && Sdc != nullptr && have % cgps::INV_LP == 0 && L.ms[have] >= 1 &&
         L.ms[have - cgps::INV_LP] >= INV_FUSED_MIN_ROWS) {

@@ -18,6 +18,7 @@
 #pragma once
 #include "cgps_decomp_tile.h"
 #include "cgps_level.h"
+#include "cgps_solve_tile.h"
 
 namespace cgps {
 
@@ -320,6 +321,91 @@ __global__ __launch_bounds__(INV_NT, INV_MIN_WAVES) void inverse_tile_kernel(con
       // couplings So[row0 - 1 .. row0 + n0 - 2]: pair index 2k <-> Sigma[2k, 2k-1], 2k+1 <-> Sigma[2k+1, 2k]
       store_pairs_coalesced<T, D>(stage, So_out + (row0 - 1) * DD, oL, even, oR, has_odd, n0, row0 == 0 ? 1 : 0);
     }
+  }
+}
+
+
+// ---- the coarse end of the recurrence in ONE launch --------------------------------------------------
+// The recurrence starts at the single row of the coarsest level and doubles the rows per level; while a
+// level has a few hundred rows a launch per level is pure latency (nine launches, 48 us, at
+// N = 2^20).  Same idea as the latency-bound passes of the solve (cgps_solve_tile.h): WHICH factor
+// blocks the levels need depends on no data, so every lane requests the D / F / G of its
+// elimination of the finest level of this kernel and of ONE deeper elimination (lane <-> elimination
+// map of deep_owner) before anything else -- one HBM round trip -- and then the levels only touch
+// LDS: Sigma of the <= INVD_TS rows stays there, row m of local level j in slot (m + 1) 2^j - 1 with
+// its diagonal block and its coupling to the PREVIOUS row of the current level.  An even row reads its
+// two odd neighbours' diagonal blocks and their coupling, writes its own diagonal block and the two
+// new couplings (inverse_even_row): disjoint slots per elimination, one barrier per level.
+// Blocks <= 256 bytes (the tile is 512 rows x 2 blocks of <= 128 bytes, or 256 rows x 2 larger blocks), one workgroup.
+// rows of the finest level this kernel takes: 512 for blocks <= 128 bytes, 256 up to 256 bytes
+template <typename T, int D> constexpr int invd_tsl() { return (size_t)D * D * sizeof(T) <= 128 ? 9 : 8; }
+constexpr int INVD_MAXLEV = 10;
+struct InverseDeepLevels {
+  int64_t offD[INVD_MAXLEV], offF[INVD_MAXLEV], offG[INVD_MAXLEV];   // packed-array offsets of the kernel's levels, finest first
+  int nlev;
+};
+// (larger blocks spill in this kernel -- 376 B per lane at fp64 d = 5 -- and gain nothing: they stay one launch per coarse level)
+template <typename T, int D> constexpr bool inverse_deep_supported() { return (size_t)D * D * sizeof(T) <= 128; }
+template <typename T, int D> constexpr size_t inverse_deep_lds_bytes() { return ((size_t)2 << invd_tsl<T, D>()) * D * D * sizeof(T); }
+
+// n: rows of the finest level (<= INVD_TS); output in natural order: Sd_out[n], So_out[n - 1]
+template <typename T, int D>
+__global__ __launch_bounds__((1 << invd_tsl<T, D>()) / 2, 1) void inverse_deep_kernel(const T* __restrict__ Dp, const T* __restrict__ Fp,
+                                                                 const T* __restrict__ Gp, InverseDeepLevels lv, int n,
+                                                                 T* __restrict__ Sd_out, T* __restrict__ So_out) {
+  constexpr int DD = D * D, INVD_TSL = invd_tsl<T, D>(), INVD_TS = 1 << INVD_TSL, INVD_NT = INVD_TS / 2;
+  extern __shared__ __attribute__((aligned(16))) char inv_smem[];
+  T* sd = reinterpret_cast<T*>(inv_smem);                 // [INVD_TS][DD]  Sigma[row, row]
+  T* so = sd + (size_t)INVD_TS * DD;                       // [INVD_TS][DD]  Sigma[row, previous row of the current level]
+  const int tid = threadIdx.x;
+  // what elimination k of local level j needs
+  auto request = [&](int j, int k, bool on, T (&L)[D][D], T (&F)[D][D], T (&G)[D][D], bool& has_odd, bool& has_left) {
+    const int nj = n >> j;
+    on = on && j < lv.nlev && k < ((nj + 1) >> 1);
+    has_odd = on && (2 * k + 1 < nj);
+    has_left = on && k >= 1;
+    if (on) load_block<T, D>(Dp + (lv.offD[j] + k) * DD, L); else set_identity<T, D>(L);
+    if (has_odd) load_block<T, D>(Fp + (lv.offF[j] + k) * DD, F); else set_zero<T, D>(F);
+    if (has_left) load_block<T, D>(Gp + (lv.offG[j] + k - 1) * DD, G); else set_zero<T, D>(G);
+    return on;
+  };
+  T L0[D][D], F0[D][D], G0[D][D], Ld[D][D], Fd[D][D], Gd[D][D];
+  bool odd0, left0, oddd, leftd;
+  const bool on0 = request(0, tid, true, L0, F0, G0, odd0, left0);
+  const DeepOwner own = deep_owner<INVD_TSL>(tid);
+  const bool ond = request(own.j, own.k, own.j >= 1, Ld, Fd, Gd, oddd, leftd);
+  auto run = [&](int j, int k, const T (&L)[D][D], const T (&F)[D][D], const T (&G)[D][D], bool has_odd, bool has_left) {
+    const int se = ((2 * k + 1) << j) - 1, st = 1 << j;   // the even row's slot, distance to its odd neighbours
+    T SdR[D][D], SoR[D][D], SdL[D][D], See[D][D], oR[D][D], oL[D][D];
+    if (has_odd) load_block<T, D>(sd + (size_t)(se + st) * DD, SdR); else set_zero<T, D>(SdR);
+    if (has_odd && has_left) load_block<T, D>(so + (size_t)(se + st) * DD, SoR); else set_zero<T, D>(SoR);
+    if (has_left) load_block<T, D>(sd + (size_t)(se - st) * DD, SdL); else set_zero<T, D>(SdL);
+    inverse_even_row<T, D>(L, F, G, SdR, SoR, SdL, has_odd, has_left, See, oR, oL);
+    store_block<T, D>(sd + (size_t)se * DD, See);
+    if (has_odd) store_block<T, D>(so + (size_t)(se + st) * DD, oR);     // the right neighbour's previous row is now this one
+    if (has_left) store_block<T, D>(so + (size_t)se * DD, oL);
+  };
+#pragma unroll 1
+  for (int j = lv.nlev - 1; j >= 1; --j) {
+    if (ond && own.j == j) run(j, own.k, Ld, Fd, Gd, oddd, leftd);
+    __syncthreads();
+  }
+  if (on0) run(0, tid, L0, F0, G0, odd0, left0);
+  __syncthreads();
+  // natural order out: 16-byte granules, consecutive threads = consecutive granules
+  constexpr int VN = Vec16<T>::N;
+  if constexpr (DD % VN == 0) {
+    using V = typename Vec16<T>::type;
+    constexpr int GR = DD / VN;
+    const V* sdv = reinterpret_cast<const V*>(sd);
+    const V* sov = reinterpret_cast<const V*>(so);
+    V* od = reinterpret_cast<V*>(Sd_out);
+    V* oo = reinterpret_cast<V*>(So_out);
+    for (int v = tid; v < n * GR; v += INVD_NT) od[v] = sdv[v];
+    for (int v = tid; v < (n - 1) * GR; v += INVD_NT) oo[v] = sov[v + GR];         // So[i] = Sigma[i+1, i]: slot i + 1
+  } else {
+    for (int v = tid; v < n * DD; v += INVD_NT) Sd_out[v] = sd[v];
+    for (int v = tid; v < (n - 1) * DD; v += INVD_NT) So_out[v] = so[v + DD];
   }
 }
 
