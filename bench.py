@@ -168,13 +168,13 @@ def extra_measurements(dev):
     cr.CHECK_POSITIVE_DEFINITE = False          # no device->host sync inside the timed calls
     out = {}
     for name, n, d, dtype, reps in (("opB_N2^20_d4_f64", 1 << 20, 4, torch.float64, 10),
-                                    ("c3_N2^22_d8_f32", 1 << 22, 8, torch.float32, 10),
+                                    ("c3_N2^22_d8_f32", 1 << 22, 8, torch.float32, 20),
                                     ("c4_N2^24_d4_f64_1gpu", 1 << 24, 4, torch.float64, 5)):
         try:
             Rs, Os, b, x_true, logdet_true = make_system(n, d, dtype, dev)
             s = Rs.element_size()
             res = {}
-            t = _time_cuda(lambda: cr.mahal_and_det(Rs, Os, b), reps)
+            t = _time_cuda(lambda: cr.mahal_and_det(Rs, Os, b), reps, warm=5)
             res["mahal_and_det_us"] = t * 1e6
             res["mahal_and_det_GBps"] = algorithmic_bytes(n, d, s) / t / 1e9
             m, ld = cr.mahal_and_det(Rs, Os, b)
