@@ -61,6 +61,10 @@ inline int64_t deep_tiles_max() {
   static PerDevice<int64_t> cus;
   return cus.get([](int dev) { return (int64_t)device_cus(dev); });
 }
+inline bool fused_top_enabled() {           // CGPS_NO_FUSED_TOP=1: separate forward / backward top passes
+  static const bool on = [] { const char* e = getenv("CGPS_NO_FUSED_TOP"); return !(e && e[0] == '1'); }();
+  return on;
+}
 inline bool deep_solve_enabled() {
   static const bool on = [] { const char* e = getenv("CGPS_NO_DEEP_SOLVE"); return !(e && e[0] == '1'); }();
   return on;
@@ -90,6 +94,10 @@ void solve_tile_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_kernel<T, D, cgps::SOLVE_LP - 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::solve_top_kernel<T, D, cgps::SOLVE_LP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::solve_top_kernel<T, D, cgps::SOLVE_LP - 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   return 1;
   });
@@ -97,7 +105,8 @@ void solve_tile_attributes() {
 
 template <typename T, int D>
 int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws,
-                       size_t ws_bytes, double* mahal_out, hipStream_t st) {
+                       size_t ws_bytes, double* mahal_out, hipStream_t st, T* const* fused_top_bufs = nullptr,
+                       bool* fused_top = nullptr) {
   LevelWs w = level_ws(N, D, sizeof(T), false, true);
   if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
   Layout L;
@@ -120,8 +129,24 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
     T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * D : nullptr;
     bool launched = false;
     if constexpr (cgps::solve_deep_supported<T, D>()) {
+      // solve(): the single-tile top pass runs its forward and its backward sweep in ONE launch
+      // (solve_top_kernel) and leaves the solution of its rows where the backward sweep expects it
+      if (fused_top_bufs != nullptr && !more && g == 1 && P.deep[p] && fused_top_enabled()) {
+        T* xtop = (p == 0) ? fused_top_bufs[2] : fused_top_bufs[p & 1];
+        if (P.ts[p] == cgps::SOLVE_TS)
+          hipLaunchKernelGGL((cgps::solve_top_kernel<T, D, cgps::SOLVE_LP>), dim3(1), dim3(cgps::SOLVE_NT), lds, st, Dp, Fp, Gp,
+                             P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, xtop, partial + 2 * pb);
+        else
+          hipLaunchKernelGGL((cgps::solve_top_kernel<T, D, cgps::SOLVE_LP - 1>), dim3(1), dim3(cgps::SOLVE_NT / 2), lds, st, Dp,
+                             Fp, Gp, P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, xtop, partial + 2 * pb);
+        launched = true;
+        *fused_top = true;
+      }
+    }
+    if constexpr (cgps::solve_deep_supported<T, D>()) {
       // few tiles (at most one per CU): the latency-bound form with every factor block requested up front
-      if (P.deep[p] && P.ts[p] == cgps::SOLVE_TS) {
+      if (launched) {
+      } else if (P.deep[p] && P.ts[p] == cgps::SOLVE_TS) {
         hipLaunchKernelGGL((cgps::halfsolve_deep_kernel<T, D, cgps::SOLVE_LP>), dim3((unsigned)g), dim3(cgps::SOLVE_NT), lds, st,
                            Dp, Fp, Gp, P.lv[p], owed_in, n_owed, spt_in, y, n, xcrr, yout, owed_out, partial + 2 * pb);
         launched = true;
@@ -152,7 +177,7 @@ int run_halfsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
 
 template <typename T, int D>
 int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws,
-                       size_t ws_bytes, hipStream_t st) {
+                       size_t ws_bytes, hipStream_t st, bool top_done = false) {
   LevelWs w = level_ws(N, D, sizeof(T), false, true);
   const size_t need = w.partial_bytes + 2 * align_up((size_t)D * sizeof(T) * w.capA);
   if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
@@ -168,6 +193,10 @@ int run_backsolve_tile(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T
   for (int p = P.np - 1; p >= 0; --p) {
     const int64_t n = P.rows[p], g = (n + P.ts[p] - 1) / P.ts[p];
     T* X = (p == 0) ? x : bufs[p & 1];
+    if (top_done && p == P.np - 1) {                     // solve_top_kernel has left this pass's solution in X
+      xc = X;
+      continue;
+    }
     bool launched = false;
     if constexpr (cgps::solve_deep_supported<T, D>()) {
       if (P.deep[p] && P.ts[p] == cgps::SOLVE_TS) {
@@ -197,15 +226,15 @@ int run_backsolve_levelwise(const T* Dp, const T* Fp, const T* Gp, int64_t N, co
 
 template <typename T, int D>
 int run_halfsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, T* xcrr, char* ws, size_t ws_bytes,
-                  double* mahal_out, hipStream_t st) {
+                  double* mahal_out, hipStream_t st, T* const* fused_top_bufs = nullptr, bool* fused_top = nullptr) {
   if (levelwise_solve_requested()) return run_halfsolve_levelwise<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
-  return run_halfsolve_tile<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st);
+  return run_halfsolve_tile<T, D>(Dp, Fp, Gp, N, y0, xcrr, ws, ws_bytes, mahal_out, st, fused_top_bufs, fused_top);
 }
 template <typename T, int D>
 int run_backsolve(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* ycrr, T* x, char* ws, size_t ws_bytes,
-                  hipStream_t st) {
+                  hipStream_t st, bool top_done = false) {
   if (levelwise_solve_requested()) return run_backsolve_levelwise<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
-  return run_backsolve_tile<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st);
+  return run_backsolve_tile<T, D>(Dp, Fp, Gp, N, ycrr, x, ws, ws_bytes, st, top_done);
 }
 
 template <typename T, int D>
@@ -449,11 +478,17 @@ int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d,
     const size_t crr = align_up((size_t)N * D * sizeof(T));
     if (ws_bytes < crr) return fail(CGPS_ERR_ARG, "workspace too small");
     T* xcrr = (T*)ws;
+    // where the backward sweep keeps the solution of pass p (run_backsolve_tile): bufs[p & 1], the
+    // caller's x for pass 0 -- the fused top pass writes there
+    const LevelWs w = level_ws(N, D, sizeof(T), false, true);
+    T* top_bufs[3] = {reinterpret_cast<T*>((char*)ws + crr + w.partial_bytes),
+                      reinterpret_cast<T*>((char*)ws + crr + w.partial_bytes + align_up((size_t)D * sizeof(T) * w.capA)), (T*)x};
+    bool top_done = false;
     int rc = run_halfsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, (const T*)y, xcrr, (char*)ws + crr,
-                                 ws_bytes - crr, nullptr, (hipStream_t)stream);
+                                 ws_bytes - crr, nullptr, (hipStream_t)stream, top_bufs, &top_done);
     if (rc != CGPS_OK) return rc;
     return run_backsolve<T, D>((const T*)Dp, (const T*)Fp, (const T*)Gp, N, xcrr, (T*)x, (char*)ws + crr,
-                               ws_bytes - crr, (hipStream_t)stream);
+                               ws_bytes - crr, (hipStream_t)stream, top_done);
   });
 }
 

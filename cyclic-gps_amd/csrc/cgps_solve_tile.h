@@ -543,4 +543,131 @@ __global__ __launch_bounds__((1 << TSL) / 2, 2) void backsolve_deep_kernel(
   }
 }
 
+
+// ---- solve(): forward AND backward sweep of the single-tile top pass in one launch -----------------
+// cgps_solve runs halfsolve and backhalfsolve back to back, and at the top of the reduction both are
+// one workgroup working on the same <= TS rows with the same factor blocks: the forward half of
+// halfsolve_deep_kernel, then -- the blocks D and F still in registers, the right-hand side of every
+// elimination being the x the forward half just produced in the same lane -- the backward half of
+// backsolve_deep_kernel; only G_k-1 (the forward half held G_k) is requested again, from L2.  One
+// launch, one prologue and one HBM round trip less.  x_top: solution of the pass's rows, natural order
+// (what the next backward pass reads as its coarse solution, or the final x of a small system).
+template <typename T, int D, int TSL>
+__global__ __launch_bounds__((1 << TSL) / 2, 2) void solve_top_kernel(
+    const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
+    const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int64_t n,
+    T* __restrict__ xcrr, T* __restrict__ x_top, double* __restrict__ partial) {
+  constexpr int DD = D * D, SOLVE_TS = 1 << TSL, SOLVE_NT = SOLVE_TS / 2;     // (shadow the single-column constants)
+  extern __shared__ __attribute__((aligned(16))) char solve_smem[];
+  T* ys = reinterpret_cast<T*>(solve_smem);                                   // [SOLVE_TS][D]
+  double* red = reinterpret_cast<double*>(solve_smem + (size_t)SOLVE_TS * D * sizeof(T));
+  const int tid = threadIdx.x;
+  const int n0 = (int)n;                                                      // one tile: n <= SOLVE_TS, row0 = 0
+  // ---- every load of the forward half (as halfsolve_deep_kernel, tile 0) -------------------------
+  T L0[D][D], F0[D][D], G0[D][D];
+  const int ne0 = (n0 + 1) >> 1, no0 = n0 >> 1;
+  const bool el0 = tid < ne0 && lv.nlev >= 1;
+  if (el0) load_block<T, D>(Dp + (lv.offD[0] + tid) * DD, L0); else set_zero_block(L0);
+  const bool upd0 = tid < no0 && lv.nlev >= 1, rgt0 = upd0 && (2 * tid + 2 < n0);
+  if (upd0) load_block<T, D>(Fp + (lv.offF[0] + tid) * DD, F0); else set_zero_block(F0);
+  if (rgt0) load_block<T, D>(Gp + (lv.offG[0] + tid) * DD, G0); else set_zero_block(G0);
+  const DeepOwner own = deep_owner<TSL>(tid);
+  const int dj = own.j, dk = own.k;
+  const int nj_d = (dj <= lv.nlev) ? (n0 >> dj) : 0;
+  const bool elim_d = dj >= 1 && dk < ((nj_d + 1) >> 1) && (dj < lv.nlev);
+  const bool upd_d = elim_d && dk < (nj_d >> 1);
+  const bool rgt_d = upd_d && (2 * dk + 2 < nj_d);
+  T Ld[D][D], Fd[D][D], Gd[D][D];
+  if (elim_d) load_block<T, D>(Dp + (lv.offD[dj] + dk) * DD, Ld); else set_zero_block(Ld);
+  if (upd_d) load_block<T, D>(Fp + (lv.offF[dj] + dk) * DD, Fd); else set_zero_block(Fd);
+  if (rgt_d) load_block<T, D>(Gp + (lv.offG[dj] + dk) * DD, Gd); else set_zero_block(Gd);
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    load_vec<T, D>(y_in + (size_t)r * D, v);
+    const int64_t wn = r + 1;
+    if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {
+      T w[D];
+      load_vec<T, D>(owed_in + (wn / spt_in) * D, w);
+#pragma unroll
+      for (int i = 0; i < D; ++i) v[i] -= w[i];
+    }
+    lds_store_vec<T, D>(ys + r * D, v);
+  }
+  __syncthreads();
+  double mah = 0.0, zero = 0.0;
+  T x0[D], xd[D];                                        // x of this lane's two eliminations (the backward half's right-hand sides)
+#pragma unroll
+  for (int i = 0; i < D; ++i) { x0[i] = T(0); xd[i] = T(0); }
+  auto eliminate = [&](int j, int k, const T (&L)[D][D], T (&x)[D]) {
+    T* slot = ys + (size_t)(((2 * k + 1) << j) - 1) * D;
+    lds_load_vec<T, D>(slot, x);
+    Chol<T, D> c;
+    chol_from_dense<T, D>(L, c);
+    fwd_subst<T, D>(c, x);
+    lds_store_vec<T, D>(slot, x);
+    if (xcrr != nullptr) store_vec<T, D>(xcrr + (lv.offD[j] + k) * D, x);
+#pragma unroll
+    for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
+  };
+  auto update = [&](int j, int k, bool right, const T (&F)[D][D], const T (&G)[D][D]) {
+    T x[D], yo[D];
+    T* slot = ys + (size_t)(((2 * k + 2) << j) - 1) * D;
+    lds_load_vec<T, D>(slot, yo);
+    lds_load_vec<T, D>(ys + (size_t)(((2 * k + 1) << j) - 1) * D, x);
+    gemv_sub<T, D>(yo, F, x);
+    if (right) {
+      lds_load_vec<T, D>(ys + (size_t)(((2 * k + 3) << j) - 1) * D, x);
+      gemv_sub<T, D>(yo, G, x);
+    }
+    lds_store_vec<T, D>(slot, yo);
+  };
+  if (el0) eliminate(0, tid, L0, x0);
+  __syncthreads();
+  for (int j = 0; j < lv.nlev; ++j) {
+    if (j == 0) { if (upd0) update(0, tid, rgt0, F0, G0); }
+    else if (dj == j && upd_d) update(j, dk, rgt_d, Fd, Gd);
+    __syncthreads();
+    if (j + 1 < lv.nlev && dj == j + 1 && elim_d) eliminate(j + 1, dk, Ld, xd);
+    __syncthreads();
+  }
+  // ---- backward half: G_k-1 of the lane's two eliminations (the forward half held G_k) -------------
+  const bool lft0 = el0 && tid >= 1, lftd = elim_d && dk >= 1;
+  if (lft0) load_block<T, D>(Gp + (lv.offG[0] + tid - 1) * DD, G0);
+  if (lftd) load_block<T, D>(Gp + (lv.offG[dj] + dk - 1) * DD, Gd);
+  // (the tile is the whole system: after the forward half every slot of an eliminated row holds its
+  // forward x, which the backward half overwrites with the solution, coarse levels first)
+  auto back = [&](int j, int k, bool right, bool left, const T (&L)[D][D], const T (&F)[D][D], const T (&G)[D][D], T (&r)[D]) {
+    T xo[D];
+    if (right) {
+      lds_load_vec<T, D>(ys + (size_t)(((2 * k + 2) << j) - 1) * D, xo);
+      gemvT_sub<T, D>(r, F, xo);
+    }
+    if (left) {
+      lds_load_vec<T, D>(ys + (size_t)(((2 * k) << j) - 1) * D, xo);
+      gemvT_sub<T, D>(r, G, xo);
+    }
+    Chol<T, D> c;
+    chol_from_dense<T, D>(L, c);
+    bwd_subst<T, D>(c, r);
+    lds_store_vec<T, D>(ys + (size_t)(((2 * k + 1) << j) - 1) * D, r);
+  };
+#pragma unroll 1
+  for (int j = lv.nlev - 1; j >= 1; --j) {
+    if (elim_d && dj == j) back(j, dk, upd_d, lftd, Ld, Fd, Gd, xd);      // 2k+1 < nj  <=>  k < nj / 2
+    __syncthreads();
+  }
+  if (el0) back(0, tid, upd0, lft0, L0, F0, G0, x0);
+  __syncthreads();
+  for (int r = tid; r < n0; r += SOLVE_NT) {
+    T v[D];
+    lds_load_vec<T, D>(ys + (size_t)r * D, v);
+    store_vec<T, D>(x_top + (size_t)r * D, v);
+  }
+  block_sum2<SOLVE_NT>(mah, zero, red);
+  if (tid == 0 && partial != nullptr) {
+    partial[2 * (size_t)blockIdx.x] = mah;
+    partial[2 * (size_t)blockIdx.x + 1] = 0.0;
+  }
+}
+
 }  // namespace cgps
