@@ -176,7 +176,19 @@ def test_not_positive_definite_raises():
     (2 ** 20 + 12345, 4, torch.float64, 1e-10),
     (2 ** 21 + 1, 5, torch.float64, 1e-10),
     (2 ** 24, 4, torch.float64, 1e-10),     # BASELINE config 4 as ONE system on one GPU (three-launch record path)
-], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64", "c4_N2^24_d4_f64"])
+    # the one-launch form (record stages inside the stage-1 kernel) for the other block sizes: with the
+    # coherent-load hand-off (even d*d in 16-byte vectors) and with the acquire hand-off (the rest)
+    (2 ** 19 + 12345, 1, torch.float64, 1e-10),
+    (2 ** 20, 2, torch.float64, 1e-10),
+    (2 ** 20 - 5, 3, torch.float64, 1e-10),
+    (2 ** 19 + 77, 2, torch.float32, 2e-5),
+    (2 ** 20, 3, torch.float32, 2e-5),
+    (2 ** 20 - 5, 6, torch.float32, 2e-5),
+    (2 ** 20, 7, torch.float32, 2e-5),
+    (2 ** 20 + 3, 6, torch.float64, 1e-10),
+    (2 ** 20, 8, torch.float64, 1e-10),
+], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64", "c4_N2^24_d4_f64", "d1_f64", "d2_f64",
+        "d3_f64", "d2_f32", "d3_f32", "d6_f32", "d7_f32", "d6_f64", "d8_f64"])
 def test_full_size_closed_form(N, d, dtype, rtol):
     """Size-independent properties at the benchmark sizes: J = L L^T with L block
     bidiagonal, so log|J| and the planted solution x_true are known in closed form."""
@@ -196,14 +208,15 @@ def test_full_size_closed_form(N, d, dtype, rtol):
     assert float((x2 - 2 * x).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-3)
 
 
-def test_folded_final_stage_never_reads_stale_records():
+@pytest.mark.parametrize("n,d", [(2 ** 20, 4), (2 ** 20, 3), (2 ** 21, 4), (2 ** 20, 8)],
+                         ids=["coherent_loads_d4", "acquire_d3", "acquire_two_per_cu_d4", "four_lanes_per_row_d8"])
+def test_folded_final_stage_never_reads_stale_records(n, d):
     """At 2^19 < N <= 2^20 rows (d = 4, fp64) the whole reduction is ONE launch: stage-1 workgroups hand
     their records to the workgroup that arrives last, inside the launch (csrc/cgps_tile.h, fold_final).
     A stale read there would go unnoticed when the same system is solved again and again (the stale
     record equals the fresh one), so alternate between DIFFERENT systems that share one workspace --
     caches warm with the other system's records -- and check every single result, bit for bit,
     against the first result of that system and against the one-launch-per-level form."""
-    n, d = 2 ** 20, 4
     systems = []
     for seed in (11, 12, 13):
         Rs, Os, b, x_true, logdet = _util.conditioned_system(n - 4096 * (seed - 11), d, seed=seed, device="cuda")
@@ -213,7 +226,7 @@ def test_folded_final_stage_never_reads_stale_records():
     cr.CHECK_POSITIVE_DEFINITE = False
     try:
         outs = []
-        for it in range(150):
+        for it in range(150 if d <= 4 else 45):
             k = (it * 7 + it // 5) % len(systems)
             Rs, Os, b, m_ref, ld_ref, logdet = systems[k]
             outs.append((k, cr.mahal_and_det(Rs, Os, b)))
