@@ -143,6 +143,115 @@ __device__ __forceinline__ void inverse_even_row(const T (&Dl)[D][D], const T (&
   mirror_lower<T, D>(See);
 }
 
+// The same algebra with its operands fetched when they are first needed and its results handed over as
+// soon as they are final (the order of the level-wise kernel, cgps_level.h): for blocks of 64 scalars
+// and more the six operands and three results of inverse_even_row do not fit in registers together.
+// load*(A) fill a block; emit*(A) take a finished one.  loadSdR / loadSdL may leave the upper triangle
+// unset (only the lower one is read).
+template <typename T, int D, class LD, class LF, class LG, class LSdR, class LSoR, class LSdL, class EoR, class EoL,
+          class ESee>
+__device__ __forceinline__ void inverse_even_row_stream(bool has_odd, bool has_left, LD&& loadD, LF&& loadF, LG&& loadG,
+                                                        LSdR&& loadSdR, LSoR&& loadSoR, LSdL&& loadSdL, EoR&& emit_oR,
+                                                        EoL&& emit_oL, ESee&& emit_See) {
+  // the three factor blocks are requested together: one HBM round trip per level, not three
+  T L[D][D], Di[D][D], See[D][D], Fb[D][D], Gb[D][D];
+  loadD(L);
+  if (has_odd) loadF(Fb);
+  if (has_left) loadG(Gb);
+  {
+    T inv[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) inv[i] = rcp_fast(L[i][i]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        if (i < j) Di[i][j] = T(0);
+        else if (i == j) Di[i][j] = inv[i];
+        else {
+          T sacc = T(0);
+#pragma unroll
+          for (int m = j; m < i; ++m) sacc = fmaT(-L[i][m], Di[m][j], sacc);
+          Di[i][j] = sacc * inv[i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {                       // lower(D^-T D^-1)
+      T sacc = T(0);
+#pragma unroll
+      for (int m = i; m < D; ++m) sacc = fmaT(Di[m][i], Di[m][j], sacc);
+      See[i][j] = sacc;
+    }
+  auto times_di = [&](T (&C)[D][D], const T (&X)[D][D]) {   // C = X D^-1
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        T sacc = T(0);
+#pragma unroll
+        for (int m = j; m < D; ++m) sacc = fmaT(X[i][m], Di[m][j], sacc);
+        C[i][j] = sacc;
+      }
+  };
+  auto acc_lower_tn = [&](const T (&X)[D][D], const T (&Y)[D][D]) {   // lower(See) += lower(X^T Y)
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        T sacc = See[i][j];
+#pragma unroll
+        for (int m = 0; m < D; ++m) sacc = fmaT(X[m][i], Y[m][j], sacc);
+        See[i][j] = sacc;
+      }
+  };
+  auto sym_times = [&](T (&C)[D][D], const T (&S)[D][D], const T (&X)[D][D]) {   // C = S X, lower(S) read
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        T sacc = T(0);
+#pragma unroll
+        for (int m = 0; m < D; ++m) sacc = fmaT(m <= i ? S[i][m] : S[m][i], X[m][j], sacc);
+        C[i][j] = sacc;
+      }
+  };
+  T Ak[D][D], Bk[D][D], Soc[D][D], M[D][D];
+  set_zero<T, D>(Ak);
+  set_zero<T, D>(Bk);
+  set_zero<T, D>(Soc);
+  if (has_odd) times_di(Ak, Fb);                         // A_k = F_k D_k^-1
+  if (has_left) times_di(Bk, Gb);                        // B_k-1 = G_k-1 D_k^-1
+  if (has_odd && has_left) loadSoR(Soc);
+  if (has_odd) {
+    loadSdR(L);
+    sym_times(M, L, Ak);
+    if (has_left) mm_acc<T, D>(M, Soc, Bk);
+    acc_lower_tn(Ak, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) L[i][j] = -M[i][j];
+    emit_oR(L);
+  }
+  if (has_left) {
+    loadSdL(L);
+    sym_times(M, L, Bk);
+    if (has_odd) mm_tn_acc<T, D>(M, Soc, Ak);
+    acc_lower_tn(Bk, M);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) L[i][j] = -M[j][i];
+    emit_oL(L);
+  }
+  mirror_lower<T, D>(See);
+  emit_See(See);
+}
+
 // Lane k holds blocks 2k (A0, if has0) and 2k+1 (A1, if has1) of dst[cnt][D*D]; blocks below
 // `first` are not written.  Through LDS (`stage`: 64 blocks), half a wave's pairs at a time, so
 // that every store instruction writes 64 x 16 consecutive bytes (see store_blocks_coalesced).
@@ -320,6 +429,204 @@ __global__ __launch_bounds__(INV_NT, INV_MIN_WAVES) void inverse_tile_kernel(con
       store_pairs_coalesced<T, D>(stage, Sd_out + row0 * DD, See, even, Sdv, has_odd, n0, 0);
       // couplings So[row0 - 1 .. row0 + n0 - 2]: pair index 2k <-> Sigma[2k, 2k-1], 2k+1 <-> Sigma[2k+1, 2k]
       store_pairs_coalesced<T, D>(stage, So_out + (row0 - 1) * DD, oL, even, oR, has_odd, n0, row0 == 0 ? 1 : 0);
+    }
+  }
+}
+
+
+// ---- the same pass for LARGE blocks (> 200 bytes: fp32 d = 8, fp64 d = 6..8) ------------------------
+// With 64 or more scalars per block the register form above spills (920 bytes per lane at fp32
+// d = 8: Sigma of the held row, its shuffled neighbours and the even row's algebra do not fit in 512
+// registers).  Here Sigma of the tile's level-1 .. level-3 rows lives in LDS instead -- slot u = the
+// level-1 row u = level-0 row 2u + 1; row m of relative level t >= 1 sits in slot (m + 1) 2^(t-1) - 1,
+// which is also the lane that computes it -- with its diagonal block and its coupling to the PREVIOUS
+// row of the current level (the scheme of inverse_deep_kernel).  An even row reads its two odd
+// neighbours' slots, writes its own diagonal block and the two new couplings: disjoint slots per
+// elimination, one barrier per level.  The registers then hold one even row's algebra only, exactly
+// what the level-wise kernel holds.  Level 0 leaves through the coalescing stage of
+// store_pairs_coalesced, which reuses the slots once every lane has read its neighbours.
+template <typename T, int D> constexpr size_t inverse_tile_lds_bytes() { return (size_t)(2 * 64 + 1) * D * D * sizeof(T); }
+
+// A slot array in LDS, one block per slot.  Lanes read and write whole blocks of neighbouring slots:
+// at a block stride of 256 or 512 bytes every lane of a 16-byte access would land on the same four
+// banks.  The 16-byte granules of slot u are therefore stored rotated by (u ^ u/4) -- distinct for the
+// 16 consecutive slots of level 0, the 16 slots 4j + 1 of level 1 and the 8 slots 8j + 3 of level 2.
+template <typename T, int D>
+struct SlotIO {
+  static constexpr int DD = D * D, VN = Vec16<T>::N;
+  static constexpr bool VEC = DD % VN == 0;
+  static constexpr int GR = VEC ? DD / VN : 1;
+  static constexpr bool SWZ = VEC && (GR & (GR - 1)) == 0 && GR >= 4;
+  static __device__ __forceinline__ int pos(int u, int g) { return u * GR + (SWZ ? (g ^ ((u ^ (u >> 2)) & (GR - 1))) : g); }
+  static __device__ __forceinline__ void load(const T* base, int u, T (&A)[D][D]) {
+    if constexpr (VEC) {
+      using V = typename Vec16<T>::type;
+      const V* b = reinterpret_cast<const V*>(base);
+#pragma unroll
+      for (int g = 0; g < GR; ++g) {
+        const V v = b[pos(u, g)];
+        const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) A[(g * VN + t) / D][(g * VN + t) % D] = e[t];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < D; ++b2) A[a][b2] = base[u * DD + a * D + b2];
+    }
+  }
+  static __device__ __forceinline__ void store(T* base, int u, const T (&A)[D][D]) {
+    if constexpr (VEC) {
+      using V = typename Vec16<T>::type;
+      V* b = reinterpret_cast<V*>(base);
+#pragma unroll
+      for (int g = 0; g < GR; ++g) {
+        V v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) e[t] = A[(g * VN + t) / D][(g * VN + t) % D];
+        b[pos(u, g)] = v;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < D; ++b2) base[u * DD + a * D + b2] = A[a][b2];
+    }
+  }
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(INV_NT, 1) void inverse_tile_lds_kernel(const T* __restrict__ Dp, const T* __restrict__ Fp,
+                                                                   const T* __restrict__ Gp, InverseLevels lv,
+                                                                   const T* __restrict__ Sd_in, const T* __restrict__ So_in,
+                                                                   int64_t n, T* __restrict__ Sd_out, T* __restrict__ So_out) {
+  constexpr int DD = D * D;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sd = reinterpret_cast<T*>(smem);                 // [64][DD]  Sigma[row, row]
+  T* so = sd + 64 * DD;                               // [64][DD]  Sigma[row, previous row of the current level]
+  T* halo = so + 64 * DD;                             // Sigma[row, row] of the previous tile's last row (an input row at every level)
+  const int lane = threadIdx.x;
+  const int64_t ntiles = (n + INV_TS - 1) / INV_TS;
+
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * INV_TS;
+    const int n0 = (int)((n - row0) < INV_TS ? (n - row0) : INV_TS);
+    const int64_t g3 = row0 >> INV_LP;
+    const int n3 = n0 >> INV_LP;
+    // input level: row m -> slot 4 (m + 1) - 1; the rows are contiguous in Sd_in / So_in
+    {
+      constexpr int VN = Vec16<T>::N;
+      const int first_o = (g3 >= 1) ? 0 : 1;          // So_in[g3 + m - 1] exists from m = first_o on
+      if constexpr (DD % VN == 0) {
+        using V = typename Vec16<T>::type;
+        constexpr int GR = DD / VN;
+        const V* gd = reinterpret_cast<const V*>(Sd_in + g3 * DD);
+        const V* go = reinterpret_cast<const V*>(So_in + (g3 - 1) * DD);
+        V* sdv = reinterpret_cast<V*>(sd);
+        V* sov = reinterpret_cast<V*>(so);
+        for (int v = lane; v < n3 * GR; v += INV_NT) {
+          const int m = v / GR, g = v % GR;
+          sdv[SlotIO<T, D>::pos(4 * (m + 1) - 1, g)] = gd[v];
+          if (m >= first_o) sov[SlotIO<T, D>::pos(4 * (m + 1) - 1, g)] = go[v];
+        }
+        if (g3 >= 1 && lane < GR) reinterpret_cast<V*>(halo)[lane] = (gd - GR)[lane];
+      } else {
+        for (int v = lane; v < n3 * DD; v += INV_NT) {
+          const int m = v / DD, e = v % DD;
+          sd[(4 * (m + 1) - 1) * DD + e] = Sd_in[g3 * DD + v];
+          if (m >= first_o) so[(4 * (m + 1) - 1) * DD + e] = So_in[(g3 - 1) * DD + v];
+        }
+        if (g3 >= 1 && lane < DD) halo[lane] = Sd_in[(g3 - 1) * DD + lane];
+      }
+    }
+    __syncthreads();
+
+    auto geom = [&](int t, bool& even, bool& has_odd, bool& has_left, int& m, int64_t& kg) {
+      if (t == 0) {
+        even = 2 * lane < n0; has_odd = 2 * lane + 1 < n0; m = 2 * lane;
+        kg = (row0 >> 1) + lane;
+      } else {
+        const int st = 1 << (t - 1);
+        const int M = n0 >> t;
+        m = ((lane + 1) >> (t - 1)) - 1;
+        const bool exists = (((lane + 1) & (st - 1)) == 0) && m < M;
+        even = exists && (m & 1) == 0;
+        kg = (row0 >> (t + 1)) + (m >> 1);
+        has_odd = even && (m + 1 < M);
+      }
+      has_left = even && kg >= 1;
+    };
+    // ---- relative levels 2 and 1: lane = slot of the row it computes ---------------------------
+#pragma unroll 1
+    for (int t = INV_LP - 1; t >= 1; --t) {
+      bool even, has_odd, has_left; int m; int64_t kg;
+      geom(t, even, has_odd, has_left, m, kg);
+      const int st = 1 << (t - 1);
+      if (even) {
+        inverse_even_row_stream<T, D>(
+            has_odd, has_left,
+            [&](T (&A)[D][D]) { load_block<T, D>(Dp + (lv.offD[t] + kg) * DD, A); },
+            [&](T (&A)[D][D]) { load_block<T, D>(Fp + (lv.offF[t] + kg) * DD, A); },
+            [&](T (&A)[D][D]) { load_block<T, D>(Gp + (lv.offG[t] + kg - 1) * DD, A); },
+            [&](T (&A)[D][D]) { SlotIO<T, D>::load(sd, lane + st, A); },
+            [&](T (&A)[D][D]) { SlotIO<T, D>::load(so, lane + st, A); },
+            [&](T (&A)[D][D]) {
+              if (m == 0) load_block<T, D>(halo, A);                       // the previous tile's last row
+              else SlotIO<T, D>::load(sd, lane - st, A);
+            },
+            [&](const T (&A)[D][D]) { SlotIO<T, D>::store(so, lane + st, A); },   // the right neighbour's previous row is now this one
+            [&](const T (&A)[D][D]) { SlotIO<T, D>::store(so, lane, A); },
+            [&](const T (&A)[D][D]) { SlotIO<T, D>::store(sd, lane, A); });
+      }
+      __syncthreads();
+    }
+
+    // ---- relative level 0: lane k computes row 2k; row 2k+1 is slot k ---------------------------
+    // Results go straight to global memory as they become final, like the level-wise kernel's (a block
+    // is two or more whole 128-byte lines): holding them for a coalescing stage costs the registers
+    // the algebra needs.
+    {
+      bool even, has_odd, has_left; int m; int64_t kg;
+      geom(0, even, has_odd, has_left, m, kg);
+      const int64_t r = row0 + 2 * lane;
+      if (even) {
+        inverse_even_row_stream<T, D>(
+            has_odd, has_left,
+            [&](T (&A)[D][D]) { load_block<T, D>(Dp + (lv.offD[0] + kg) * DD, A); },
+            [&](T (&A)[D][D]) { load_block<T, D>(Fp + (lv.offF[0] + kg) * DD, A); },
+            [&](T (&A)[D][D]) { load_block<T, D>(Gp + (lv.offG[0] + kg - 1) * DD, A); },
+            [&](T (&A)[D][D]) { SlotIO<T, D>::load(sd, lane, A); },
+            [&](T (&A)[D][D]) { SlotIO<T, D>::load(so, lane, A); },
+            [&](T (&A)[D][D]) {
+              if (lane == 0) load_block<T, D>(halo, A);
+              else SlotIO<T, D>::load(sd, lane - 1, A);
+            },
+            [&](const T (&A)[D][D]) { store_block<T, D>(So_out + r * DD, A); },          // Sigma[2k+1, 2k]
+            [&](const T (&A)[D][D]) { store_block<T, D>(So_out + (r - 1) * DD, A); },    // Sigma[2k, 2k-1]
+            [&](const T (&A)[D][D]) { store_block<T, D>(Sd_out + r * DD, A); });
+      }
+      // Sigma[2u+1, 2u+1] = slot u, unchanged: consecutive lanes copy consecutive 16-byte granules
+      const int nodd = n0 >> 1;
+      constexpr int VN = Vec16<T>::N;
+      if constexpr (DD % VN == 0) {
+        using V = typename Vec16<T>::type;
+        constexpr int GR = DD / VN;
+        const V* sdv = reinterpret_cast<const V*>(sd);
+        V* od = reinterpret_cast<V*>(Sd_out + row0 * DD);
+        for (int v = lane; v < nodd * GR; v += INV_NT) {
+          const int u = v / GR, g = v % GR;
+          od[(size_t)(2 * u + 1) * GR + g] = sdv[SlotIO<T, D>::pos(u, g)];
+        }
+      } else {
+        for (int v = lane; v < nodd * DD; v += INV_NT) {
+          const int u = v / DD, e = v % DD;
+          Sd_out[(row0 + 2 * u + 1) * DD + e] = sd[u * DD + e];
+        }
+      }
+      __syncthreads();
     }
   }
 }

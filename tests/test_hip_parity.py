@@ -111,12 +111,13 @@ def test_ragged_sizes_against_oracle(d, dtype):
 
 
 @pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float64), (4, torch.float64),
-                                     (4, torch.float32), (5, torch.float32), (6, torch.float64), (8, torch.float32)],
-                         ids=["d1f64", "d2f64", "d3f64", "d4f64", "d4f32", "d5f32", "d6f64", "d8f32"])
+                                     (4, torch.float32), (5, torch.float32), (5, torch.float64), (6, torch.float64),
+                                     (7, torch.float64), (8, torch.float32), (8, torch.float64)],
+                         ids=["d1f64", "d2f64", "d3f64", "d4f64", "d4f32", "d5f32", "d5f64", "d6f64", "d7f64", "d8f32", "d8f64"])
 def test_inverse_blocks_fused_passes(d, dtype):
-    """inverse_blocks at sizes where the three-levels-per-launch passes run (blocks of <= 128
-    bytes: one, two and three fused passes, ragged one-row tiles, rows of a level that are not a
-    multiple of 8); the larger blocks stay level-wise and are checked at the same sizes."""
+    """inverse_blocks at sizes where the three-levels-per-launch passes run: one, two and three fused
+    passes, ragged one-row tiles, rows of a level that are not a multiple of 8.  Blocks up to 200 bytes
+    keep a tile's Sigma in registers, larger ones (fp32 d = 8, fp64 d = 6..8) in LDS."""
     tol = dict(rtol=1e-9, atol=1e-10) if dtype == torch.float64 else dict(rtol=3e-4, atol=3e-4)
     for n in (1024, 1025, 1031, 4097, 8191, 8200, 65537, 66049, 100003, 524289 if d == 4 else 70001):
         Rs, Os, _, _, _ = _util.conditioned_system(n, d, seed=7 + n)
