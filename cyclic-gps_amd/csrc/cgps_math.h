@@ -269,6 +269,54 @@ __device__ __forceinline__ void store_block(T* __restrict__ p, const T (&A)[D][D
   }
 }
 
+// RG consecutive blocks / vectors whose total size is a multiple of 16 bytes, from a 16-byte aligned address
+template <typename T, int D, int RG>
+__device__ __forceinline__ void load_rows(const T* __restrict__ p, T (&A)[RG][D][D]) {
+  constexpr int VN = Vec16<T>::N, DD = D * D;
+  static_assert((RG * DD) % VN == 0, "a row group must fill whole 16-byte granules");
+  using V = typename Vec16<T>::type;
+  const V* q = reinterpret_cast<const V*>(p);
+  T flat[RG * DD];
+#pragma unroll
+  for (int i = 0; i < RG * DD / VN; ++i) {
+    V v = q[i];
+    const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int t = 0; t < VN; ++t) flat[i * VN + t] = e[t];
+  }
+#pragma unroll
+  for (int r = 0; r < RG; ++r)
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) A[r][i][j] = flat[r * DD + i * D + j];
+}
+template <typename T, int D, int RG>
+__device__ __forceinline__ void load_row_vecs(const T* __restrict__ p, T (&y)[RG][D]) {
+  constexpr int VN = Vec16<T>::N;
+  if constexpr ((RG * D) % VN == 0) {
+    using V = typename Vec16<T>::type;
+    const V* q = reinterpret_cast<const V*>(p);
+    T flat[RG * D];
+#pragma unroll
+    for (int i = 0; i < RG * D / VN; ++i) {
+      V v = q[i];
+      const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int t = 0; t < VN; ++t) flat[i * VN + t] = e[t];
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[r][i] = flat[r * D + i];
+  } else {
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int i = 0; i < D; ++i) y[r][i] = p[r * D + i];
+  }
+}
+
 template <typename T, int D>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p, T (&v)[D]) {
 #pragma unroll

@@ -500,6 +500,20 @@ __device__ __forceinline__ void write_partial(double mah, double logp, int failr
   }
 }
 
+// dev-only wall-clock stamps of the final reduction (dev_bench.hip defines CGPS_FIN_STAMPS; no stamp
+// executes in the library build)
+#ifdef CGPS_FIN_STAMPS
+static __device__ long long g_fin_stamps[16];
+static __device__ long long g_k_stamps[512][12];
+static __device__ int g_k_xcc[512];
+#define CGPS_KSTAMP(k) do { if (threadIdx.x == 0) { g_k_stamps[blockIdx.x][k] = wall_clock64(); \
+  if ((k) == 0) g_k_xcc[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11))); } } while (0)
+#define CGPS_FSTAMP(k) do { if (FINAL && threadIdx.x == 0) g_fin_stamps[k] = wall_clock64(); } while (0)
+#else
+#define CGPS_FSTAMP(k) do { } while (0)
+#define CGPS_KSTAMP(k) do { } while (0)
+#endif
+
 // The update a lane computed for the row left of its chunk belongs to the previous lane's
 // kept row: fetch it from lane+1 (wave-local shuffle; LDS across the wave boundary) and add it.
 // The tile's last real lane keeps its row as is (its update arrives with the next tile's record).
@@ -588,7 +602,9 @@ __device__ __forceinline__ void reduce_staged_tile_and_emit(LdsTile<T, D>& t, in
   using RL = RecordLayout<T, D>;
   const int tid = threadIdx.x;
   __syncthreads();
+  CGPS_KSTAMP(8);
   const int levels = tile_cr<T, D, NT>(t, n_real, pl, mah, fail);
+  CGPS_KSTAMP(9);
   // the record, one block element per lane (every parked block is stored symmetric): D*D lanes of
   // wave 0 instead of thread 0 walking the levels one after the other
   if (rec_out != nullptr && tid < D * D) {
@@ -634,24 +650,17 @@ struct StageSmem {
   }
 };
 
-// dev-only wall-clock stamps of the final reduction (dev_bench.hip defines CGPS_FIN_STAMPS; no stamp
-// executes in the library build)
-#ifdef CGPS_FIN_STAMPS
-static __device__ long long g_fin_stamps[16];
-static __device__ long long g_k_stamps[512][8];
-static __device__ int g_k_xcc[512];
-#define CGPS_KSTAMP(k) do { if (threadIdx.x == 0) { g_k_stamps[blockIdx.x][k] = wall_clock64(); \
-  if ((k) == 0) g_k_xcc[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11))); } } while (0)
-#define CGPS_FSTAMP(k) do { if (FINAL && threadIdx.x == 0) g_fin_stamps[k] = wall_clock64(); } while (0)
-#else
-#define CGPS_FSTAMP(k) do { } while (0)
-#define CGPS_KSTAMP(k) do { } while (0)
-#endif
 
 // ---- stage 1 -----------------------------------------------------------------------------
 // (two workgroups per CU = two waves per SIMD: the streaming phase needs the second wave to
 // cover HBM latency when the grid is larger than the chip, so registers are capped at 256)
 // (blocks up to 4x4 fp64 / 5x5 fp32 fit that budget; larger ones get the whole register file)
+// rows a lane of stage 1 takes per group of vector loads (see chunk_reduce_kernel): blocks that are not a
+// multiple of 16 bytes, where the 2 or 4 operand sets still fit the register budget
+template <typename T, int D> constexpr int stage1_row_group() {
+  if (sizeof(T) == 8 && (D == 3 || D == 5)) return 2;     // 110 -> 104 us (d = 3), 209 -> 204 us (d = 5) at 2^20 rows
+  return 1;                                                 // fp32 d = 3 in groups of 4: no faster (87 us), one wave per SIMD fewer
+}
 template <typename T, int D> constexpr int stage1_min_waves() {
   return ((sizeof(T) == 8 && D <= 4) || (sizeof(T) == 4 && D <= 5)) ? 2 : 1;
 }
@@ -792,17 +801,65 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
       for (int g = 0; g < YR * D / Vec16<T>::N; ++g) dst[g] = src[g];
     }
   };
+  constexpr int RG = stage1_row_group<T, D>();
+  constexpr bool GROUPED = RG > 1 && C % RG == 0 && !YSTAGE;
+  const bool grouped = GROUPED && (r0 + C <= N - 1);      // every row of the chunk, and O[r0 + C - 1], exist
   if (r0 < N) {
-    load_block<T, D>(Rg + r0 * DD, Rc);
-    if (yfull) {
-      stage_y_line(r0);
-      load_vec<T, D>(ylds, yc);
-    } else {
-      load_vec<T, D>(yg + r0 * D, yc);
+    if (!grouped) {
+      load_block<T, D>(Rg + r0 * DD, Rc);
+      if (yfull) {
+        stage_y_line(r0);
+        load_vec<T, D>(ylds, yc);
+      } else {
+        load_vec<T, D>(yg + r0 * D, yc);
+      }
     }
     if (r0 >= 1) load_block<T, D>(Og + (r0 - 1) * DD, Cc);
     else if (Oleft != nullptr) load_block<T, D>(Oleft, Cc);
   }
+  // Blocks whose size is not a multiple of 16 bytes (odd d) are read with scalar loads above and below:
+  // 55 load instructions per row at fp64 d = 5.  RG = 2 consecutive rows of such an fp64 system DO fill
+  // whole 16-byte granules and start on a 16-byte boundary when the first of them has an even index,
+  // which a lane's chunk guarantees (C % RG == 0).  A lane whose chunk is complete therefore takes its
+  // rows RG at a time with vector loads (half the instructions): R[a .. a+RG), y[a .. a+RG) and
+  // O[a .. a+RG), O[a+i] being the coupling of row a+i to row a+i+1 -- the last of the group is carried
+  // into the next group.  (A few per cent only: at one wave per SIMD the stage is bound by the waves'
+  // own chains, and 70 of the 177 us at d = 5 are the record stages -- dev_bench -DDEVB_D=5 20 2 1.)
+  if constexpr (GROUPED) {
+    if (grouped) {
+      T Oc[D][D];                              // O[a - 1], carried
+#pragma unroll 1
+      for (int p = 0; p < C / RG; ++p) {
+        const int64_t a = r0 + (int64_t)RG * p;
+        T Rq[RG][D][D], Oq[RG][D][D], yq[RG][D];
+        load_rows<T, D, RG>(Rg + a * DD, Rq);
+        load_rows<T, D, RG>(Og + a * DD, Oq);
+        load_row_vecs<T, D, RG>(yg + a * D, yq);
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+          if (i == 0) {
+            if (p > 0) {
+              eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, Oc, Rq[0], yq[0], pl, mah, fail);
+            } else {                           // the chunk's first row
+#pragma unroll
+              for (int u = 0; u < D; ++u) {
+                yc[u] = yq[0][u];
+#pragma unroll
+                for (int v = 0; v < D; ++v) Rc[u][v] = Rq[0][u][v];
+              }
+            }
+          } else {
+            eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, Oq[i - 1], Rq[i], yq[i], pl, mah, fail);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+#pragma unroll
+          for (int v = 0; v < D; ++v) Oc[u][v] = Oq[RG - 1][u][v];
+      }
+    }
+  }
+  if (!grouped) {
 #pragma unroll 1
   for (int j = 0; j < C - 1; ++j) {
     const int64_t rn = r0 + j + 1;
@@ -817,6 +874,7 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
       load_vec<T, D>(yg + rn * D, yn);
     }
     eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
+  }
   }
   // (the tile is written only after the workgroup-wide barrier inside reduce_tile_and_emit: no lane
   // is still reading its y line then)

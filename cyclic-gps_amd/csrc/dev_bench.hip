@@ -9,6 +9,9 @@
 #include <vector>
 
 #define CGPS_FIN_STAMPS 1
+#ifndef DEVB_D
+#define DEVB_D 4          // block size of the tile_cr and timeline modes (-DDEVB_D=5 ...)
+#endif
 #include "cgps_tile.h"
 
 using namespace cgps;
@@ -159,7 +162,7 @@ static void run_mfma_probe() {
 template <int NTHR, int MW>
 __global__ __launch_bounds__(NTHR) void tilecr_bench_kernel(int n_real, int reps, long long* ticks, double* sums) {
   using T = double;
-  constexpr int D = 4;
+  constexpr int D = DEVB_D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   StageSmem<T, D, 256, NTHR> sm(smem);
   const int tid = threadIdx.x;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(NTHR) void tilecr_bench_kernel(int n_real, int reps
 
 template <int NTHR, int MW>
 void run_tilecr(int grid, hipStream_t st) {
-  const size_t lds = stage_lds_bytes<double, 4>(256, NTHR);
+  const size_t lds = stage_lds_bytes<double, DEVB_D>(256, NTHR);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tilecr_bench_kernel<NTHR, MW>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long long* ticks;
@@ -256,7 +259,7 @@ void run_chunk_variants(const T* R, const T* O, const T* y, int64_t N, double* o
 
 int main(int argc, char** argv) {
   using T = double;
-  constexpr int D = 4;
+  constexpr int D = DEVB_D;
   const int lg = argc > 1 ? atoi(argv[1]) : 20;
   const int64_t N = (int64_t)1 << lg;
   if (argc > 2 && atoi(argv[2]) == 2) {           // dev_bench 20 2: stamps inside the final reduction of the real pipeline
@@ -291,7 +294,7 @@ int main(int argc, char** argv) {
         double o[2];
         CK(hipMemcpy(o, out2, 16, hipMemcpyDeviceToHost));
         if (it >= 28) {
-          static long long ks[512][8];
+          static long long ks[512][12];
           CK(hipMemcpyFromSymbol(ks, HIP_SYMBOL(g_k_stamps), sizeof(ks)));
           long long t0 = ks[0][0];
           for (int b = 0; b < 256; ++b) t0 = ks[b][0] < t0 ? ks[b][0] : t0;
@@ -309,9 +312,9 @@ int main(int argc, char** argv) {
           printf("\n   stream end by block index (us):");
           for (int b = 0; b < 256; b += 17) printf(" b%d:%.1f", b, (ks[b][1] - t0) * 0.01);
           printf("\n");
-          const char* names[8] = {"start", "streamed", "tile reduced+emitted", "partial written", "arrived(group)",
-                                  "group reduced", "arrived(top)", "final done"};
-          for (int k = 0; k < 8; ++k) {
+          const char* names[10] = {"start", "streamed", "tile reduced+emitted", "partial written", "arrived(group)",
+                                   "group reduced", "arrived(top)", "final done", "rows staged in LDS", "tile_cr done"};
+          for (int k = 0; k < 10; ++k) {
             long long lo = 1LL << 62, hi = 0;
             int cnt = 0;
             for (int b = 0; b < 256; ++b) {
