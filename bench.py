@@ -259,6 +259,14 @@ def extra_measurements(dev):
                "log_likelihood_us": _time_cuda(lambda: leg.log_likelihood(m, ts, xs), 10) * 1e6,
                "insample_posterior_us": _time_cuda(lambda: leg.insample_posterior(m, ts, xs), 10) * 1e6,
                "ll_rel_err_vs_reference": abs(float(ll) - float(g["ll"])) / abs(float(g["ll"]))}
+        # the same evaluation captured in a HIP graph and replayed (leg.GraphedLogLikelihood)
+        try:
+            gll = leg.GraphedLogLikelihood(m, ts, xs)
+            res["log_likelihood_graph_replay_us"] = _time_cuda(gll, 20) * 1e6
+            res["graph_ll_rel_err_vs_reference"] = abs(float(gll()) - float(g["ll"])) / abs(float(g["ll"]))
+            del gll
+        except Exception as e:
+            res["log_likelihood_graph_replay_us"] = "error: " + repr(e)[:160]
         # the same evaluation with a gradient wanted (operands from cgps_peg_precision through its
         # analytic adjoint, csrc/cgps_leg.h), and a whole training step: forward + backward to the parameters
         mg = leg.LEGMatrices(*(t(k).requires_grad_(True) for k in ("N", "R", "B", "Lambda")))

@@ -732,6 +732,14 @@ __device__ __forceinline__ void fold_record_stages(char* smem, int* last_flag, T
     double* gpartial = partial + PARTIAL_STRIDE * (size_t)gridDim.x;       // the groups' partial results
     const bool lead = arrive(&g_fold_counter[fold.slot][1 + grp], gsize);
     CGPS_KSTAMP(4);
+    if (gridDim.x == 1) {
+      // a single tile: its one record is what the top stage would be handed
+      // (whole systems only: the host keeps a one-tile SHARD on the two-launch path)
+      record_reduce_body<T, D, FOLD_MAX_GROUPS, NW, true, COH>(smem, 0u, rec, (int64_t)1, 1, (T*)nullptr, (double*)nullptr,
+                                                               partial, (int64_t)1, fold.out2, fold.info, rows_per_tile, N,
+                                                               (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
+      return;
+    }
     if (lead) {
       record_reduce_body<T, D, FOLD_GROUP, NW, false, COH>(smem, grp, rec, (int64_t)gridDim.x, 1, grec, gpartial,
                                                            (const double*)nullptr, (int64_t)0, (double*)nullptr,
@@ -1227,9 +1235,15 @@ void tile_set_attributes() {
     }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 8, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 8, Cfg::NT1, Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 4, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 4, Cfg::NT1, Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 1, Cfg::NT1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 1, Cfg::NT1, Cfg::NT1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>),
@@ -1307,15 +1321,29 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     }
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
                        dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
-  } else if (csel == 1)
-    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 1, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
-  else if (csel == 4)
-    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 4, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
-  else if (csel == 8)
-    hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 8, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
-                       Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+  } else if (csel != Cfg::C) {
+    // small systems (fewer rows per lane, at most one workgroup per CU): the same one-launch form --
+    // no faster on the GPU's clock than two launches (measured 2^14 .. 2^19 rows), but one node in a
+    // caller's HIP graph and one launch on the host; a single tile (N <= 2048) finishes in place
+    const int slot = (fold_final_enabled() && !(shard_record != nullptr && tiles == 1)) ? fold_slot_for(ws) : -1;
+    const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
+    auto launch = [&](auto cs) {
+      constexpr int CS = decltype(cs)::value;
+      if (slot >= 0)
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, CS, Cfg::NT1, Cfg::NT1, true>), dim3((unsigned)tiles), dim3(Cfg::NT1),
+                           lds1, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      else
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, CS, Cfg::NT1>), dim3((unsigned)tiles), dim3(Cfg::NT1), lds1, st,
+                           Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+    };
+    if (csel == 1) launch(std::integral_constant<int, 1>{});
+    else if (csel == 4) launch(std::integral_constant<int, 4>{});
+    else launch(std::integral_constant<int, 8>{});
+    if (slot >= 0) {
+      if (ev_stop) (void)hipEventRecord(ev_stop, st);
+      return 0;
+    }
+  }
   else {
     // up to FOLD_GROUP * FOLD_MAX_GROUPS stage-1 workgroups: the record stages run inside the
     // launch (fold_final), for a whole system and for one shard of a larger one alike

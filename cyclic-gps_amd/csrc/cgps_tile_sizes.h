@@ -23,6 +23,10 @@ inline int64_t tile_rows1(int d, size_t s) {
 // the same number of records for the final stage or fewer).
 constexpr int64_t STAGE1_SMALL_TILES = 256;
 inline int stage1_rows_per_lane(int64_t N, int c_full, int lanes) {
+  // a few hundred rows: ONE workgroup (a second one costs an inter-workgroup hand-off, ~10 us, to save
+  // three or seven eliminations of ~1 us per lane)
+  if (c_full > 4 && N > lanes && N <= (int64_t)lanes * 4) return 4;
+  if (c_full > 8 && N > lanes && N <= (int64_t)lanes * 8) return 8;
   if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 1) return 1;
   if (c_full > 4 && N <= STAGE1_SMALL_TILES * lanes * 4) return 4;
   if (c_full > 8 && N <= STAGE1_SMALL_TILES * lanes * 8) return 8;

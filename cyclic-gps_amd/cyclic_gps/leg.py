@@ -44,7 +44,9 @@ class LEGMatrices:
         """(Lambda Lambda^T + 1e-9 I)^-1, obs_dim x obs_dim, used through plain matrix products
         (torch.linalg.solve's GPU backward faults on ROCm 7.0 for a 1x1 system with hundreds of
         right-hand sides; the inverse's backward is matmul only)."""
-        return torch.linalg.inv(self.LLT)
+        if self.Lambda.shape[0] == 1:                 # a single output: no factorisation call (and none inside a HIP graph)
+            return 1.0 / self.LLT
+        return torch.linalg.inv_ex(self.LLT)[0]       # inv_ex: no error check, hence no device->host synchronisation
 
     @property
     def LLT(self):
@@ -146,13 +148,45 @@ def log_likelihood(m, ts, xs):
     Li = m.LLT_inv
     xl = xs @ Li
     llt_mahal = (xl * xs).sum()
-    llt_det = torch.logdet(2 * math.pi * LLT) * xs.shape[0]
+    llt_det = (torch.log(2 * math.pi * LLT[0, 0]) if LLT.shape[0] == 1 else torch.logdet(2 * math.pi * LLT)) * xs.shape[0]
     v = (xl @ m.B).contiguous()
     Rs, Os = peg_precision(ts, m.G)
     _, sig_inv_det = cr.mahal_and_det(Rs, Os, torch.zeros_like(v))       # = det(decompose(Rs, Os)), fused
     K_Rs = Rs + (m.B.T @ Li @ m.B).unsqueeze(0)
     k_mahal, k_det = cr.mahal_and_det(Rs=K_Rs, Os=Os, x=v)
     return -0.5 * ((llt_mahal - k_mahal) + (llt_det + k_det - sig_inv_det))
+
+
+class GraphedLogLikelihood:
+    """``log_likelihood(m, ts, xs)`` captured once in a HIP graph and replayed: an optimiser's or a
+    sampler's evaluation loop over fixed shapes then costs one graph launch instead of ~25 kernel
+    launches and the Python between them (N ~ 500 is launch-bound: BASELINE config 5).
+
+    The graph reads ``m``'s four matrices, ``ts`` and ``xs`` from the tensors given here: change them IN
+    PLACE (``copy_``) between replays.  Positive-definiteness is not checked inside the graph (the check
+    reads a device word on the host); a non-PD system shows up as NaN / inf in ``value``.  No gradient."""
+
+    def __init__(self, m, ts, xs, warmup=2):
+        prev = cr.CHECK_POSITIVE_DEFINITE
+        cr.CHECK_POSITIVE_DEFINITE = False
+        try:
+            with torch.no_grad():
+                side = torch.cuda.Stream(device=ts.device)
+                side.wait_stream(torch.cuda.current_stream(ts.device))
+                with torch.cuda.stream(side):                   # workspaces and library handles exist before capture
+                    for _ in range(warmup):
+                        log_likelihood(m, ts, xs)
+                torch.cuda.current_stream(ts.device).wait_stream(side)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.value = log_likelihood(m, ts, xs)
+        finally:
+            cr.CHECK_POSITIVE_DEFINITE = prev
+
+    def __call__(self):
+        """Replay; returns the 0-d tensor the graph writes (same tensor every time)."""
+        self.graph.replay()
+        return self.value
 
 
 def insample_posterior(m, ts, xs):

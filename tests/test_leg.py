@@ -67,6 +67,22 @@ def test_likelihood_and_posterior_on_gpu(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_log_likelihood_replayed_from_a_hip_graph(name):
+    """leg.GraphedLogLikelihood: the captured evaluation replays to the reference's value, and follows an
+    in-place change of the data and of a parameter (what an optimiser loop does between replays)."""
+    g, m, ts, xs = _load(name, device="cuda")
+    gll = leg.GraphedLogLikelihood(m, ts, xs)
+    for _ in range(3):
+        assert abs(float(gll()) - float(g["ll"])) <= 1e-8 * abs(float(g["ll"]))
+    xs.mul_(1.25)
+    m.Lambda.mul_(1.5)
+    eager = float(leg.log_likelihood(m, ts, xs))
+    assert abs(eager - float(g["ll"])) > 1e-3 * abs(float(g["ll"]))        # the change matters
+    assert abs(float(gll()) - eager) <= 1e-10 * abs(eager)
+
+
+@pytest.mark.gpu
 def test_posterior_mean_fp32_within_1e4():
     """north_star: posterior mean within 1e-4 in fp32."""
     g, m, ts, xs = _load("leg_co2like", device="cuda", dtype=torch.float32)
