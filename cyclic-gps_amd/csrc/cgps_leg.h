@@ -173,6 +173,198 @@ __global__ __launch_bounds__(LEG_THREADS) void peg_precision_kernel(const T* __r
 }
 
 
+// ---- prediction glue (the step AFTER the cyclic reduction) ----------------------------
+// Posterior of the latent at arbitrary target times from the in-sample posterior (mean[n][d], diagonal
+// covariance blocks P[n][d][d], lower off-diagonal blocks C[n-1][d][d] = Cov(z_{i+1}, z_i)): the
+// reference walks the targets in a Python loop (intercast, models.py:455-514: searchsorted, one or two
+// matrix exponentials, one gaussian_stitch of a 2d x 2d or 3d x 3d Gaussian, model_utils.py:64-107).
+// Here one lane per target, everything in registers, and the stitches reduced to d x d algebra:
+//   forecast from a neighbour with posterior N(mu, P) over a gap with E = exp(-1/2 gap G)
+//   (E transposed when the target lies BEFORE the first observation):
+//       mean = E mu,   cov = I - E E^T + E P E^T
+//   interpolation between neighbours j-1 (mu0, P0) and j (mu1, P1), C = Cov(z_j, z_j-1),
+//   E1 = exp(-1/2 (t - t_j-1) G), E2 = exp(-1/2 (t_j - t) G), E3 = E1 E2: the prior of
+//   (z_j-1, z_j) has covariance [[I, E3^T], [E3, I]], whose inverse through the Schur complement
+//   S = I - E3 E3^T (symmetric positive definite) gives the 2d-wide mean transformer as two d x d blocks
+//       W = (E2^T - E1 E3^T) S^-1,   Ma = E1 - W E3,   Mb = W
+//       mean = Ma mu0 + Mb mu1
+//       cov  = I - (Ma E1^T + Mb E2) + Ma P0 Ma^T + Ma C^T Mb^T + Mb C Ma^T + Mb P1 Mb^T
+// Branches as the reference takes them: t before the first / after the last observation -> forecast;
+// t at the first / last observation (torch.allclose defaults: |a - b| <= 1e-8 + 1e-5 |b|) -> the
+// in-sample values; otherwise interpolation between searchsorted's neighbours.
+template <typename T, int D>
+__device__ __forceinline__ void leg_forecast(const T (&E)[D][D], const T* __restrict__ mu, const T* __restrict__ Pg,
+                                             T (&mean)[D], T (&cov)[D][D]) {
+  T P[D][D], EP[D][D];
+  load_block<T, D>(Pg, P);
+  mat_mul<T, D>(EP, E, P);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    T s = T(0);
+#pragma unroll
+    for (int m = 0; m < D; ++m) s = fmaT(E[i][m], mu[m], s);
+    mean[i] = s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      T c = (i == j) ? T(1) : T(0);
+#pragma unroll
+      for (int m = 0; m < D; ++m) c = fmaT(EP[i][m] - E[i][m], E[j][m], c);   // + (E P - E) E^T
+      cov[i][j] = c;
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(LEG_THREADS) void leg_intercast_kernel(const T* __restrict__ ts, int64_t n,
+                                                                    const T* __restrict__ tt, int64_t p,
+                                                                    const T* __restrict__ Gg, const T* __restrict__ mu,
+                                                                    const T* __restrict__ Pd, const T* __restrict__ Co,
+                                                                    T* __restrict__ out_mean, T* __restrict__ out_cov) {
+  constexpr int DD = D * D;
+  const int64_t k = (int64_t)blockIdx.x * LEG_THREADS + threadIdx.x;
+  if (k >= p) return;
+  const T t = tt[k];
+  int64_t lo = 0, hi = n;                          // first index with ts[idx] >= t (torch.searchsorted, right = False)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (ts[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  const int64_t idx = lo;
+  auto close = [](T a, T b) {
+    const T dlt = a > b ? a - b : b - a, ab = b < T(0) ? -b : b;
+    return dlt <= T(1e-8) + T(1e-5) * ab;
+  };
+  const T t_first = ts[0], t_last = ts[n - 1];
+  const bool at_first = idx == 0 && close(t, t_first);
+  const bool at_last = idx > 0 && close(t, t_last);
+  const bool back = idx == 0 && !at_first, fwd = idx == n && !at_last;
+  T mean[D], cov[D][D];
+  if (at_first || at_last) {
+    const int64_t r = at_first ? 0 : n - 1;
+    load_vec<T, D>(mu + r * D, mean);
+    load_block<T, D>(Pd + r * DD, cov);
+  } else {
+    T G[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) G[a][b] = Gg[a * D + b];
+    auto exp_gap = [&](T gap, T (&E)[D][D]) {
+      T A[D][D];
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) A[a][b] = T(-0.5) * gap * G[a][b];
+      mat_exp<T, D>(E, A);
+    };
+    if (back || fwd) {
+      T E[D][D];
+      exp_gap(back ? t_first - t : t - t_last, E);
+      if (back) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = a + 1; b < D; ++b) { const T v = E[a][b]; E[a][b] = E[b][a]; E[b][a] = v; }
+      }
+      const int64_t r = back ? 0 : n - 1;
+      T m0[D];
+      load_vec<T, D>(mu + r * D, m0);
+      leg_forecast<T, D>(E, m0, Pd + r * DD, mean, cov);
+    } else {
+      int64_t j = idx < 1 ? 1 : idx;
+      if (j > n - 1) j = n - 1;
+      T E1[D][D], E2[D][D], E3[D][D], W[D][D], Ma[D][D];
+      exp_gap(t - ts[j - 1], E1);
+      exp_gap(ts[j] - t, E2);
+      mat_mul<T, D>(E3, E1, E2);
+      {
+        T S[D][D], Xt[D][D], Wt[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) {
+            T s = T(0), x = E2[a][b];              // X^T[a][b] = X[b][a] = E2[a][b] - (E1 E3^T)[b][a]
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+              s = fmaT(E3[a][m], E3[b][m], s);     // (E3 E3^T)[a][b]
+              x = fmaT(-E1[b][m], E3[a][m], x);
+            }
+            S[a][b] = s;
+            Xt[a][b] = x;
+          }
+        (void)spd_solve_i_minus<T, D>(S, Xt, Wt);  // W^T = S^-1 X^T
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) W[a][b] = Wt[b][a];
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          T s = E1[a][b];
+#pragma unroll
+          for (int m = 0; m < D; ++m) s = fmaT(-W[a][m], E3[m][b], s);
+          Ma[a][b] = s;
+        }
+      T m0[D], m1[D];
+      load_vec<T, D>(mu + (j - 1) * D, m0);
+      load_vec<T, D>(mu + j * D, m1);
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        T s = T(0);
+#pragma unroll
+        for (int m = 0; m < D; ++m) s = fmaT(Ma[a][m], m0[m], fmaT(W[a][m], m1[m], s));
+        mean[a] = s;
+      }
+      // cov = I - (Ma E1^T + W E2) + (Ma P0 + W C) Ma^T + (Ma C^T + W P1) W^T
+      T Q[D][D], U[D][D], V[D][D];
+      load_block<T, D>(Pd + (j - 1) * DD, Q);      // P0
+      mat_mul<T, D>(U, Ma, Q);
+      load_block<T, D>(Co + (j - 1) * DD, Q);      // C
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          T u = U[a][b], v = T(0);
+#pragma unroll
+          for (int m = 0; m < D; ++m) {
+            u = fmaT(W[a][m], Q[m][b], u);         // + W C
+            v = fmaT(Ma[a][m], Q[b][m], v);        // Ma C^T
+          }
+          U[a][b] = u;
+          V[a][b] = v;
+        }
+      load_block<T, D>(Pd + j * DD, Q);            // P1
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          T v = V[a][b];
+#pragma unroll
+          for (int m = 0; m < D; ++m) v = fmaT(W[a][m], Q[m][b], v);
+          V[a][b] = v;
+        }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          T c = (a == b) ? T(1) : T(0);
+#pragma unroll
+          for (int m = 0; m < D; ++m) {
+            c = fmaT(-Ma[a][m], E1[b][m], c);      // - Ma E1^T
+            c = fmaT(-W[a][m], E2[m][b], c);       // - W E2
+            c = fmaT(U[a][m], Ma[b][m], c);        // + U Ma^T
+            c = fmaT(V[a][m], W[b][m], c);         // + V W^T
+          }
+          cov[a][b] = c;
+        }
+    }
+  }
+  store_vec<T, D>(out_mean + k * D, mean);
+  store_block<T, D>(out_cov + k * DD, cov);
+}
+
 // ---- adjoint of the assembly (training through the path, reference models.py:374-381) -----------------
 // Given gRs[N] = d loss / d Rs and gOs[N-1] = d loss / d Os, one lane per time gap i recomputes the
 // gap's E, a, b and walks the expressions above backwards:

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "cgps_mahal_logdet_adjoint": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "cgps_peg_precision": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
     "cgps_peg_precision_adjoint": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "cgps_leg_intercast": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgps_record_elems": (_int, [_int, _int, ctypes.POINTER(_i64)]),
     "cgps_shard_reduce": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),
     "cgps_finish_records": (_int, [_vp, _sz, _vp, _sz, _i64, _i64, _i64, _int, _int, _vp, _vp, _vp]),

@@ -24,6 +24,8 @@ The in-sample posterior itself (``decompose`` / ``solve`` / ``inverse_blocks``) 
 (``leg.insample_posterior``).  Pinned by ``tests/golden/leg_*.npz`` (``pp_mean``, ``pp_cov``,
 ``pred_mean``, ``pred_cov`` recorded from the reference's own ``make_predictions``).
 """
+import os
+
 import torch
 
 from . import leg
@@ -87,6 +89,22 @@ def interpolate(eG1, eG2, prev_ip_mean, prev_ip_cov_diag, prev_ip_cov_offdiag, n
     return gaussian_stitch(joint_latent_mean, joint_latent_cov, joint_ip_mean, joint_ip_cov)
 
 
+def _intercast_hip(G, ip_mean, Rs, Os, ts, target_ts):
+    """All targets in one HIP kernel (cgps_leg_intercast, csrc/cgps_leg.h): one lane per target, the two
+    matrix exponentials and the stitch in registers.  No autograd graph (prediction is inference)."""
+    from . import _hip
+    dt, dev = ip_mean.dtype, ip_mean.device
+    n, d, p = ip_mean.shape[0], G.shape[0], target_ts.shape[0]
+    c = lambda t: t.detach().to(device=dev, dtype=dt).contiguous()   # noqa: E731
+    ts_, tt_, G_, mu_, Rs_, Os_ = c(ts), c(target_ts), c(G), c(ip_mean), c(Rs), c(Os)
+    means = torch.empty(p, d, dtype=dt, device=dev)
+    covs = torch.empty(p, d, d, dtype=dt, device=dev)
+    _hip.check(_hip.lib().cgps_leg_intercast(_hip.ptr(ts_), n, _hip.ptr(tt_), p, _hip.ptr(G_), d, _hip.dtype_code(dt),
+                                             _hip.ptr(mu_), _hip.ptr(Rs_), _hip.ptr(Os_), _hip.ptr(means),
+                                             _hip.ptr(covs), _hip.stream_ptr()))
+    return means, covs
+
+
 def intercast(m, ip_mean, ip_cov, ts, target_ts, thresh=1e-10, check_sorted=True):
     """Posterior of the latent at every target time from the in-sample posterior
     (reference models.py:455-514; ``thresh`` is accepted and unused there as well).
@@ -96,9 +114,11 @@ def intercast(m, ip_mean, ip_cov, ts, target_ts, thresh=1e-10, check_sorted=True
     one device->host read in here; check_sorted=False skips it).  Returns (means [p, rank],
     covs [p, rank, rank]).  Branches per target, as the reference takes them: before the first
     observation (backward forecast), after the last (forward forecast), at the first / last
-    observation (in-sample values), otherwise interpolation between the two neighbours.  Every
-    branch is evaluated for every target with clamped (harmless) arguments and the results are
-    selected with masks, so no branch decision leaves the device."""
+    observation (in-sample values), otherwise interpolation between the two neighbours.
+    On the GPU: one HIP kernel, a lane per target (``_intercast_hip``).  On CPU tensors (or with a
+    gradient wanted, or CGPS_LEG_TORCH_INTERCAST=1) batched torch ops: every branch is evaluated for
+    every target with clamped (harmless) arguments and the results are selected with masks, so no
+    branch decision leaves the device."""
     Rs, Os = (ip_cov["Rs"], ip_cov["Os"]) if isinstance(ip_cov, dict) else ip_cov
     G = m.G
     n, rank = ts.shape[0], G.shape[0]
@@ -106,6 +126,10 @@ def intercast(m, ip_mean, ip_cov, ts, target_ts, thresh=1e-10, check_sorted=True
     if check_sorted:
         assert bool((target_ts[1:] - target_ts[:-1] > 0).all())      # reference :471
     p = target_ts.shape[0]
+    if (ip_mean.is_cuda and 1 <= rank <= 8 and ip_mean.dtype in (torch.float32, torch.float64)
+            and os.environ.get("CGPS_LEG_TORCH_INTERCAST") != "1"
+            and not (torch.is_grad_enabled() and any(t.requires_grad for t in (ip_mean, Rs, Os, G, ts, target_ts)))):
+        return _intercast_hip(G, ip_mean, Rs, Os, ts, target_ts)
     idx = torch.searchsorted(ts, target_ts)
     close = lambda a, b: (a - b).abs() <= 1e-8 + 1e-5 * b.abs()      # noqa: E731  torch.allclose(a, b) defaults
     at_first = (idx == 0) & close(target_ts, ts[0])

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CGPS_VERSION 200
+#define CGPS_VERSION 210
 
 enum { CGPS_F32 = 0, CGPS_F64 = 1 };
 
@@ -149,6 +149,17 @@ int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtyp
  * receives d loss / d (t_{i+1} - t_i).  N >= 2.  No workspace. */
 int cgps_peg_precision_adjoint(const void* ts, const void* G, int64_t N, int d, int dtype,
                                const void* gRs, const void* gOs, void* gG_partial, void* gtau, void* stream);
+
+/* Prediction glue of LEG models, the step AFTER the path (reference models.py:455-514 intercast with
+ * forecast :394-408, interpolate :410-452 and gaussian_stitch model_utils.py:64-107, which the reference
+ * runs as a Python loop over the targets): posterior mean and covariance of the latent at p target
+ * times from the in-sample posterior.  ts[n] sorted; target_ts[p]; G[d][d]; ip_mean[n][d];
+ * ip_cov_diag[n][d][d]; ip_cov_offdiag[n-1][d][d] = Cov(z_{i+1}, z_i) (what cgps_inverse_blocks leaves
+ * in So)  ->  out_mean[p][d], out_cov[p][d][d].  One lane per target; no workspace, no info word (the
+ * systems solved are positive definite whenever ts is strictly increasing). */
+int cgps_leg_intercast(const void* ts, int64_t n, const void* target_ts, int64_t p, const void* G, int d, int dtype,
+                       const void* ip_mean, const void* ip_cov_diag, const void* ip_cov_offdiag,
+                       void* out_mean, void* out_cov, void* stream);
 
 /* ---- time-axis sharding (one shard per GPU / rank) -----------------------------------------
  * The reference has no distributed code; this is the multi-GPU form BASELINE.json asks for.

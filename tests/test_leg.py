@@ -189,6 +189,50 @@ def test_make_predictions_on_gpu(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_hip_intercast_matches_reference_given_its_insample_posterior(name):
+    """cgps_leg_intercast alone: fed the reference's own in-sample posterior it reproduces the reference's
+    predictive posterior at every target (all five branches occur in the fixtures' targets)."""
+    predict, g, m, ts, xs, target_ts, mean, cov = _check_predictions(name, "cuda")
+    pm, pv = predict.intercast(m, mean, cov, ts, target_ts)
+    assert pm.device.type == "cuda"
+    np.testing.assert_allclose(pm.cpu().numpy(), g["pp_mean"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pv.cpu().numpy(), g["pp_cov"], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float32), (4, torch.float64),
+                                     (5, torch.float64), (6, torch.float32), (7, torch.float64), (8, torch.float64)])
+def test_hip_intercast_against_torch_ops(d, dtype, monkeypatch):
+    """Every rank and both dtypes, irregular times, targets before / at / between / exactly on / after the
+    observations, n = 1 included: the kernel against the batched torch form of the same glue."""
+    from cyclic_gps import predict
+    gen = torch.Generator().manual_seed(100 + d)
+    Nm = torch.tril(torch.randn(d, d, generator=gen, dtype=torch.float64)) * 0.4 + torch.eye(d, dtype=torch.float64)
+    Rm = torch.tril(torch.randn(d, d, generator=gen, dtype=torch.float64), -1) * 0.3
+    tol = dict(rtol=1e-9, atol=1e-11) if dtype == torch.float64 else dict(rtol=2e-3, atol=2e-4)
+    for n in (1, 2, 37):
+        ts = torch.cumsum(0.2 + torch.rand(n, generator=gen, dtype=torch.float64), 0)
+        inner = (ts[:-1] + (ts[1:] - ts[:-1]) * torch.rand(max(n - 1, 0), generator=gen, dtype=torch.float64))
+        tt = torch.cat([ts[:1] - 1.3, ts[:1] - 0.1, ts[:1], inner, ts[n // 2:n // 2 + 1] if n > 2 else ts[:0],
+                        ts[-1:] if n > 1 else ts[:0], ts[-1:] + 0.4, ts[-1:] + 2.0])
+        tt = torch.unique(tt)                                           # sorted, strictly increasing
+        A = torch.randn(n, d, d, generator=gen, dtype=torch.float64) * 0.2
+        Rs = A @ A.transpose(-1, -2) + 0.5 * torch.eye(d, dtype=torch.float64)
+        Os = torch.randn(max(n - 1, 0), d, d, generator=gen, dtype=torch.float64) * 0.05
+        mu = torch.randn(n, d, generator=gen, dtype=torch.float64)
+        m = leg.LEGMatrices(Nm.to(dtype).cuda(), Rm.to(dtype).cuda(), torch.ones(1, d, dtype=dtype).cuda(),
+                            torch.ones(1, 1, dtype=dtype).cuda())
+        args = (m, mu.to(dtype).cuda(), (Rs.to(dtype).cuda(), Os.to(dtype).cuda()), ts.to(dtype).cuda(), tt.to(dtype).cuda())
+        hm, hv = predict.intercast(*args)
+        monkeypatch.setenv("CGPS_LEG_TORCH_INTERCAST", "1")
+        rm, rv = predict.intercast(*args)
+        monkeypatch.delenv("CGPS_LEG_TORCH_INTERCAST")
+        np.testing.assert_allclose(hm.cpu().numpy(), rm.cpu().numpy(), err_msg="n=%d" % n, **tol)
+        np.testing.assert_allclose(hv.cpu().numpy(), rv.cpu().numpy(), err_msg="n=%d" % n, **tol)
+
+
+@pytest.mark.gpu
 def test_make_predictions_fp32_within_1e4():
     predict, g, m, ts, xs, target_ts, _, _ = _check_predictions("leg_co2like", "cuda")
     m32 = leg.LEGMatrices(*(t.float() for t in (m.N, m.R, m.B, m.Lambda)))
