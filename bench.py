@@ -277,6 +277,14 @@ def extra_measurements(dev):
             for p_ in (mg.N, mg.R, mg.B, mg.Lambda):
                 p_.grad = None
         res["log_likelihood_fwd_bwd_us"] = _time_cuda(train_step, 5) * 1e6
+        try:      # the same training evaluation captured in a HIP graph (leg.GraphedValueAndGrad)
+            gv = leg.GraphedValueAndGrad(mg, ts, xs)
+            res["log_likelihood_fwd_bwd_graph_replay_us"] = _time_cuda(gv, 20) * 1e6
+            del gv
+            for p_ in (mg.N, mg.R, mg.B, mg.Lambda):
+                p_.grad = None
+        except Exception as e:
+            res["log_likelihood_fwd_bwd_graph_replay_us"] = "error: " + repr(e)[:160]
         from cyclic_gps import predict
         tt = torch.from_numpy(g["target_ts"]).to(dev) if "target_ts" in g.files else ts
         pm = predict.make_predictions(m, ts, xs, tt)[0]

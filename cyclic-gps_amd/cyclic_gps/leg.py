@@ -189,6 +189,46 @@ class GraphedLogLikelihood:
         return self.value
 
 
+class GraphedValueAndGrad:
+    """One training evaluation -- ``ll = log_likelihood(m, ts, xs); ll.backward()`` -- captured in a HIP
+    graph (forward through the fused kernels, backward through ``solve`` + ``inverse_blocks`` + the two
+    analytic adjoints).  ``m``'s four matrices must be leaf tensors that require a gradient; the graph
+    leaves d ll / d (N, R, B, Lambda) in their ``.grad`` (overwritten at every replay) and ll in ``value``.
+    Update the matrices / data in place between replays (an optimiser's ``step()`` does).  As with
+    ``GraphedLogLikelihood`` nothing is checked on the host inside the graph."""
+
+    def __init__(self, m, ts, xs, warmup=3):
+        self.params = [m.N, m.R, m.B, m.Lambda]
+        if not all(p.is_leaf and p.requires_grad for p in self.params):
+            raise ValueError("the four LEG matrices must be leaf tensors with requires_grad=True")
+        prev = cr.CHECK_POSITIVE_DEFINITE
+        cr.CHECK_POSITIVE_DEFINITE = False
+        try:
+            cur = torch.cuda.current_stream(ts.device)
+            side = torch.cuda.Stream(device=ts.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    for p in self.params:
+                        p.grad = None
+                    log_likelihood(m, ts, xs).backward()
+            cur.wait_stream(side)
+            for p in self.params:
+                p.grad = None                               # the capture allocates the gradients in the graph's pool
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.value = log_likelihood(m, ts, xs)
+                self.value.backward()
+            self.grads = [p.grad for p in self.params]
+        finally:
+            cr.CHECK_POSITIVE_DEFINITE = prev
+
+    def __call__(self):
+        """Replay; returns (ll, [d ll / d N, d ll / d R, d ll / d B, d ll / d Lambda]) -- the same tensors every time."""
+        self.graph.replay()
+        return self.value, self.grads
+
+
 def insample_posterior(m, ts, xs):
     """Posterior mean [N,d] and (diag, lower off-diag) covariance blocks (models.py:282-298)."""
     K_Rs, K_Os = posterior_precision(m, ts)

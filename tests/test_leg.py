@@ -83,6 +83,33 @@ def test_log_likelihood_replayed_from_a_hip_graph(name):
 
 
 @pytest.mark.gpu
+def test_training_evaluation_replayed_from_a_hip_graph():
+    """leg.GraphedValueAndGrad: forward + backward captured once; the replayed gradients are the reference's
+    autograd gradients, and follow an in-place parameter update."""
+    g, m, ts, xs = _load("leg_co2like", device="cuda")
+    mg = leg.LEGMatrices(*(t.clone().requires_grad_(True) for t in (m.N, m.R, m.B, m.Lambda)))
+    gv = leg.GraphedValueAndGrad(mg, ts, xs)
+    for _ in range(2):
+        ll, grads = gv()
+        assert abs(float(ll.detach()) - float(g["grad_ll"])) <= 1e-8 * abs(float(g["grad_ll"]))
+        # (the fixture holds the gradients of the reference's triangular parametrisation)
+        for got, key in ((grads[0].tril(), "gN"), (grads[1].tril(-1), "gR"), (grads[2], "gB"), (grads[3].tril(), "gLambda")):
+            np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-6, atol=1e-7, err_msg=key)
+    with torch.no_grad():
+        mg.N.mul_(1.1)
+        mg.B.add_(0.05)
+    ll, grads = gv()
+    replayed = [float(ll.detach())] + [t.clone() for t in grads]
+    for p_ in gv.params:
+        p_.grad = None
+    eager = leg.log_likelihood(mg, ts, xs)
+    eager.backward()
+    assert abs(replayed[0] - float(eager.detach())) <= 1e-10 * abs(float(eager.detach()))
+    for got, p_ in zip(replayed[1:], gv.params):
+        np.testing.assert_allclose(got.cpu().numpy(), p_.grad.cpu().numpy(), rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.gpu
 def test_posterior_mean_fp32_within_1e4():
     """north_star: posterior mean within 1e-4 in fp32."""
     g, m, ts, xs = _load("leg_co2like", device="cuda", dtype=torch.float32)
