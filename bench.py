@@ -290,6 +290,13 @@ def extra_measurements(dev):
         pm = predict.make_predictions(m, ts, xs, tt)[0]
         res["make_predictions_us"] = _time_cuda(lambda: predict.make_predictions(m, ts, xs, tt), 5) * 1e6
         res["make_predictions_targets"] = int(tt.shape[0])
+        try:      # posterior + predictions captured in a HIP graph (leg.Graphed)
+            gp = leg.Graphed(predict.make_predictions, m, ts, xs, tt, check_sorted=False)
+            res["make_predictions_graph_replay_us"] = _time_cuda(gp, 20) * 1e6
+            res["graph_prediction_mean_max_abs_err"] = float((gp()[0] - pm).abs().max())
+            del gp
+        except Exception as e:
+            res["make_predictions_graph_replay_us"] = "error: " + repr(e)[:160]
         if "pred_mean" in g.files:
             res["prediction_mean_max_abs_err_vs_reference"] = float((pm.cpu() - torch.from_numpy(g["pred_mean"])).abs().max())
         if "post_mean" in g.files:

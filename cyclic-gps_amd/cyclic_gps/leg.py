@@ -157,36 +157,46 @@ def log_likelihood(m, ts, xs):
     return -0.5 * ((llt_mahal - k_mahal) + (llt_det + k_det - sig_inv_det))
 
 
-class GraphedLogLikelihood:
-    """``log_likelihood(m, ts, xs)`` captured once in a HIP graph and replayed: an optimiser's or a
-    sampler's evaluation loop over fixed shapes then costs one graph launch instead of ~25 kernel
-    launches and the Python between them (N ~ 500 is launch-bound: BASELINE config 5).
+class Graphed:
+    """``fn(*args, **kwargs)`` of this harness (``log_likelihood``, ``insample_posterior``,
+    ``predict.make_predictions`` ...) captured once in a HIP graph and replayed: an evaluation loop over
+    fixed shapes then costs one graph launch instead of the function's 25-60 kernel launches and the Python
+    between them (N ~ 500 is launch-bound: BASELINE config 5).
 
-    The graph reads ``m``'s four matrices, ``ts`` and ``xs`` from the tensors given here: change them IN
-    PLACE (``copy_``) between replays.  Positive-definiteness is not checked inside the graph (the check
-    reads a device word on the host); a non-PD system shows up as NaN / inf in ``value``.  No gradient."""
+    The graph reads its inputs from the tensors given here: change them IN PLACE (``copy_``) between
+    replays.  Positive-definiteness is not checked inside the graph (the check reads a device word on the
+    host); a non-PD system shows up as NaN / inf in the results.  No gradient.  ``fn`` must not read
+    device values on the host (``predict.make_predictions(..., check_sorted=False)``)."""
 
-    def __init__(self, m, ts, xs, warmup=2):
+    def __init__(self, fn, *args, warmup=2, **kwargs):
+        dev = next(a.device for a in args if isinstance(a, torch.Tensor))
         prev = cr.CHECK_POSITIVE_DEFINITE
         cr.CHECK_POSITIVE_DEFINITE = False
         try:
             with torch.no_grad():
-                side = torch.cuda.Stream(device=ts.device)
-                side.wait_stream(torch.cuda.current_stream(ts.device))
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):                   # workspaces and library handles exist before capture
                     for _ in range(warmup):
-                        log_likelihood(m, ts, xs)
-                torch.cuda.current_stream(ts.device).wait_stream(side)
+                        fn(*args, **kwargs)
+                torch.cuda.current_stream(dev).wait_stream(side)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
-                    self.value = log_likelihood(m, ts, xs)
+                    self.value = fn(*args, **kwargs)
         finally:
             cr.CHECK_POSITIVE_DEFINITE = prev
 
     def __call__(self):
-        """Replay; returns the 0-d tensor the graph writes (same tensor every time)."""
+        """Replay; returns what ``fn`` returned at capture (the same tensors every time)."""
         self.graph.replay()
         return self.value
+
+
+class GraphedLogLikelihood(Graphed):
+    """``log_likelihood(m, ts, xs)`` as a replayable HIP graph (see ``Graphed``); ``value`` is the 0-d result."""
+
+    def __init__(self, m, ts, xs, warmup=2):
+        super().__init__(log_likelihood, m, ts, xs, warmup=warmup)
 
 
 class GraphedValueAndGrad:

@@ -160,15 +160,17 @@ def intercast(m, ip_mean, ip_cov, ts, target_ts, thresh=1e-10, check_sorted=True
     return means, covs
 
 
-def predictive_posterior(m, ts, xs, target_ts):
+def predictive_posterior(m, ts, xs, target_ts, check_sorted=True):
     """E[z(t) | x] and Cov[z(t) | x] at every target   (reference models.py:516-528).  The in-sample
     posterior is decompose + solve + inverse_blocks on the HIP path."""
     mean, (cRs, cOs) = leg.insample_posterior(m, ts, xs)
-    return intercast(m, mean, {"Rs": cRs, "Os": cOs}, ts, target_ts)
+    return intercast(m, mean, {"Rs": cRs, "Os": cOs}, ts, target_ts, check_sorted=check_sorted)
 
 
-def make_predictions(m, ts, xs, target_ts):
+def make_predictions(m, ts, xs, target_ts, check_sorted=True):
     """Predicted observation mean [p, obs_dim] and covariance [p, obs_dim, obs_dim] at the targets
-    (reference models.py:530-546: the latent's B-image; the observation noise is not added there)."""
-    pm, pv = predictive_posterior(m, ts, xs, target_ts)
+    (reference models.py:530-546: the latent's B-image; the observation noise is not added there).
+    check_sorted=False skips the reference's assertion on the targets (:471), the one device->host read:
+    the call is then capturable in a HIP graph (``leg.Graphed``)."""
+    pm, pv = predictive_posterior(m, ts, xs, target_ts, check_sorted=check_sorted)
     return pm @ m.B.T, m.B.unsqueeze(0) @ pv @ m.B.T.unsqueeze(0)

@@ -83,6 +83,22 @@ def test_log_likelihood_replayed_from_a_hip_graph(name):
 
 
 @pytest.mark.gpu
+def test_predictions_replayed_from_a_hip_graph():
+    """leg.Graphed(predict.make_predictions, ..., check_sorted=False): posterior (decompose, solve,
+    inverse_blocks) and the intercast kernel in one replayable graph."""
+    predict, g, m, ts, xs, target_ts, _, _ = _check_predictions("leg_co2like", "cuda")
+    gp = leg.Graphed(predict.make_predictions, m, ts, xs, target_ts, check_sorted=False)
+    for _ in range(2):
+        pm, pv = gp()
+        np.testing.assert_allclose(pm.cpu().numpy(), g["pred_mean"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(pv.cpu().numpy(), g["pred_cov"], rtol=1e-6, atol=1e-7)
+    xs.mul_(0.5)                                     # new data, same shapes
+    pm, _ = gp()
+    em, _ = predict.make_predictions(m, ts, xs, target_ts)
+    np.testing.assert_allclose(pm.cpu().numpy(), em.cpu().numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
 def test_training_evaluation_replayed_from_a_hip_graph():
     """leg.GraphedValueAndGrad: forward + backward captured once; the replayed gradients are the reference's
     autograd gradients, and follow an in-place parameter update."""
