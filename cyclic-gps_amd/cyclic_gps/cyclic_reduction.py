@@ -31,11 +31,14 @@ from . import _hip
 
 JITTER = None  # reference :13 (passed to psd_safe_cholesky there; no jitter retry here)
 
-try:  # raise the caller's own exception class when gpytorch is installed
-    from gpytorch.utils.errors import NotPSDError  # type: ignore
+try:  # raise the caller's own exception classes when gpytorch is installed
+    from gpytorch.utils.errors import NanError, NotPSDError  # type: ignore
 except Exception:  # pragma: no cover
     class NotPSDError(RuntimeError):
         """A diagonal block was not positive definite."""
+
+    class NanError(RuntimeError):
+        """The blocks handed in hold NaN (what psd_safe_cholesky raises in the reference, :227,306,429)."""
 
 # Set to False to skip the device->host read of the `info` word after a
 # factorisation (removes one stream synchronisation per call).  Nothing raises then:
@@ -75,10 +78,17 @@ def _check_blocks(Rs, Os):
     _hip.dtype_code(Rs.dtype)
 
 
-def _raise_if_not_pd(info):
+def _raise_if_not_pd(info, *blocks):
+    """The reference's error behaviour at its psd_safe_cholesky calls: NanError when the operands hold NaN,
+    NotPSDError otherwise (its jitter-and-retry in between is not reproduced).  `blocks` are looked at only
+    on the failure path."""
     if CHECK_POSITIVE_DEFINITE:
         bad = int(info.item())
         if bad != 0:
+            for t in blocks:
+                nan = int(torch.isnan(t).sum().item()) if t is not None and t.numel() else 0
+                if nan:
+                    raise NanError("%d of %d elements of the %s tensor are NaN." % (nan, t.numel(), tuple(t.shape)))
             raise NotPSDError("block row %d is not positive definite" % (bad - 1))
 
 
@@ -138,7 +148,7 @@ def decompose_step(Rs, Os):
     _hip.check(_hip.lib().cgps_decompose_step(
         _hip.ptr(R), _hip.ptr(O), n, d, _hip.dtype_code(dt), _hip.ptr(D), _hip.ptr(F), _hip.ptr(G),
         _hip.ptr(Rn), _hip.ptr(On), _hip.ptr(info), _hip.stream_ptr()))
-    _raise_if_not_pd(info)
+    _raise_if_not_pd(info, R, O)
     b = lambda t: _back(t, Rs)  # noqa: E731
     return (n, b(D), b(F), b(G)), (b(Rn), b(On))
 
@@ -172,7 +182,7 @@ def _decompose_raw(Rs, Os):
     _hip.check(_hip.lib().cgps_decompose(
         _hip.ptr(R), _hip.ptr(O), N, d, _hip.dtype_code(dt), _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp),
         _hip.ptr(ws), nbytes, _hip.ptr(info), _hip.stream_ptr()))
-    _raise_if_not_pd(info)
+    _raise_if_not_pd(info, R, O)
     ms, Ds, Fs, Gs = _views(Dp, Fp, Gp, N)
     if Rs.device.type != "cuda":
         Ds, Fs, Gs = ([_back(t, Rs) for t in lst] for lst in (Ds, Fs, Gs))
@@ -303,7 +313,7 @@ def _mahal_and_det(Rs, Os, x, levelwise):
     fn = _hip.lib().cgps_mahal_logdet_levelwise if levelwise else _hip.lib().cgps_mahal_logdet
     _hip.check(fn(_hip.ptr(R), _hip.ptr(O), _hip.ptr(v), N, d, _hip.dtype_code(dt), _hip.ptr(ws), nbytes,
                   _hip.ptr(out), _hip.ptr(info), _hip.stream_ptr()))
-    _raise_if_not_pd(info)
+    _raise_if_not_pd(info, R, O)
     res = _back(out.to(dt), Rs)
     return res[0], res[1]
 

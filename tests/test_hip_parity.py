@@ -155,9 +155,11 @@ def test_not_positive_definite_raises():
         cr.decompose(Rs.cuda(), Os.cuda())
     with pytest.raises(cr.NotPSDError):
         cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
-    Rs[17] = float("nan")
-    with pytest.raises(cr.NotPSDError):
+    Rs[17] = float("nan")                         # the reference's psd_safe_cholesky raises NanError for NaN operands
+    with pytest.raises(cr.NanError):
         cr.mahal_and_det(Rs.cuda(), Os.cuda(), b.cuda())
+    with pytest.raises(cr.NanError):
+        cr.decompose(Rs.cuda(), Os.cuda())
     # without the host-side check (no device sync) the results are poisoned, never plausible:
     # two negative pivots multiply to a positive "determinant"
     Rs, Os, b, _, _ = _util.conditioned_system(5000, 4)
