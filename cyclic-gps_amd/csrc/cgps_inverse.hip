@@ -4,6 +4,7 @@
 #include "cgps_host.h"
 #include "cgps_tile.h"
 #include "cgps_inverse_tile.h"
+#include "cgps_inverse_quad.h"
 
 using namespace cgps_host;
 
@@ -13,6 +14,10 @@ namespace {
 #endif
 inline bool inverse_deep_enabled() {        // CGPS_NO_DEEP_INVERSE=1: one launch per coarse level (A/B timing)
   static const bool on = [] { const char* e = getenv("CGPS_NO_DEEP_INVERSE"); return !(e && e[0] == '1'); }();
+  return on;
+}
+inline bool inverse_quad_enabled() {        // CGPS_NO_QUAD_INVERSE=1: 8 x 8 blocks one lane per row (A/B timing)
+  static const bool on = [] { const char* e = getenv("CGPS_NO_QUAD_INVERSE"); return !(e && e[0] == '1'); }();
   return on;
 }
 inline bool inverse_lds_enabled() {         // CGPS_NO_LDS_INVERSE=1: large blocks one launch per level (A/B timing)
@@ -35,19 +40,30 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   // (cgps_inverse_tile.h): those passes read 1/8 of what they write instead of ping-ponging every
   // level's Sigma through HBM.
   // blocks up to CGPS_INV_FUSED_MAX_BLOCK bytes keep the tile's Sigma in registers, larger ones in LDS
-  constexpr bool FUSED = (size_t)D * D * sizeof(T) <= 400;        // fp64 d = 8 (512-byte blocks) spills in either form: level-wise
+  // 8 x 8 blocks: four lanes per row (cgps_inverse_quad.h); fp64 d = 8 one lane per row spills in either form
+  const bool IN_QUAD = D == 8 && inverse_quad_enabled();
+  const bool FUSED = (size_t)D * D * sizeof(T) <= 400 || IN_QUAD;
   static const size_t reg_max = [] {                  // CGPS_INV_REG_MAX_BLOCK=<bytes>: A/B timing of the two forms
     const char* e = getenv("CGPS_INV_REG_MAX_BLOCK");
     return e ? (size_t)atoi(e) : (size_t)CGPS_INV_FUSED_MAX_BLOCK;
   }();
   const bool IN_LDS = (size_t)D * D * sizeof(T) > reg_max;
-  const size_t lds = IN_LDS ? cgps::inverse_tile_lds_bytes<T, D>() : (size_t)64 * D * D * sizeof(T);
+  size_t lds = IN_LDS ? cgps::inverse_tile_lds_bytes<T, D>() : (size_t)64 * D * D * sizeof(T);
   auto* tile_kernel = IN_LDS ? &cgps::inverse_tile_lds_kernel<T, D> : &cgps::inverse_tile_kernel<T, D>;
-  static PerDevice<int> grid_caps[2];                 // persistent waves: what this device holds at once
-  const int grid_cap = grid_caps[IN_LDS].get([&](int dev) {
+  int tile_threads = cgps::INV_NT;
+  if constexpr (D == 8) {
+    if (IN_QUAD) {
+      lds = cgps::inverse_quad_lds_bytes<T>();
+      if constexpr (sizeof(T) == 4) tile_kernel = &cgps::inverse_tile_quad_kernel<T, 64>;
+      else tile_kernel = &cgps::inverse_tile_quad_wg_kernel<T>;
+      tile_threads = cgps::inverse_quad_threads<T>();
+    }
+  }
+  static PerDevice<int> grid_caps[3];                 // persistent workgroups: what this device holds at once
+  const int grid_cap = grid_caps[IN_QUAD ? 2 : (IN_LDS ? 1 : 0)].get([&](int dev) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int nb = 2;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile_kernel, cgps::INV_NT, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile_kernel, tile_threads, lds);
     return device_cus(dev) * (nb > 0 ? nb : 1);
   });
   int p = 0;
@@ -89,7 +105,7 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
   }
   for (int l = l_start; l >= 0;) {
     const int have = l + 1;                               // Sdc / Soc hold Sigma of this level
-    if (FUSED && (!IN_LDS || inverse_lds_enabled()) && Sdc != nullptr && have % cgps::INV_LP == 0 && L.ms[have] >= 1 &&
+    if (FUSED && (IN_QUAD || !IN_LDS || inverse_lds_enabled()) && Sdc != nullptr && have % cgps::INV_LP == 0 && L.ms[have] >= 1 &&
         L.ms[have - cgps::INV_LP] >= INV_FUSED_MIN_ROWS) {
       const int lf = have - cgps::INV_LP;
       const int64_t n = L.ms[lf], tiles = (n + cgps::INV_TS - 1) / cgps::INV_TS;
@@ -100,7 +116,7 @@ int run_inverse(const T* Dp, const T* Fp, const T* Gp, int64_t N, T* Sd, T* So, 
       T* od = (lf == 0) ? Sd : bufs[p];
       T* oo = (lf == 0) ? So : bufs[p] + cap * D * D;
       const int64_t grid = tiles < grid_cap ? tiles : grid_cap;
-      hipLaunchKernelGGL(tile_kernel, dim3((unsigned)grid), dim3(cgps::INV_NT), lds, st, Dp, Fp, Gp, lv, Sdc, Soc, n, od, oo);
+      hipLaunchKernelGGL(tile_kernel, dim3((unsigned)grid), dim3(tile_threads), lds, st, Dp, Fp, Gp, lv, Sdc, Soc, n, od, oo);
       Sdc = od; Soc = oo; p ^= 1;
       l = lf - 1;
       continue;
