@@ -56,6 +56,9 @@ __device__ __forceinline__ T quad_sum(T v) {
 }
 
 // threads per 128-row tile: one wave (16 quads, several rounds per level) at fp32, four waves at fp64
+#ifndef CGPS_INVQ_AHEAD
+#define CGPS_INVQ_AHEAD 1
+#endif
 template <typename T> constexpr int inverse_quad_threads() { return sizeof(T) == 4 ? 64 : 256; }
 template <typename T> constexpr size_t inverse_quad_lds_bytes() {
   return (size_t)(2 * 64 + 1 + inverse_quad_threads<T>() / 4) * 64 * sizeof(T);   // slots, halo, one transposing block per quad
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(NT, 1) void inverse_tile_quad_kernel(
   using SIO = SlotIO<T, 8>;
   using V = typename Vec16<T>::type;
   constexpr int D = 8, DD = 64, RP = 2, VN = Vec16<T>::N, GR = DD / VN, NQ = NT / 4;
-  constexpr bool AHEAD = true;                       // a second set of factor registers: the next round's blocks are on their way
+  constexpr bool AHEAD = CGPS_INVQ_AHEAD;            // a second set of factor registers: the next round's blocks are on their way
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sd = reinterpret_cast<T*>(smem);                 // [64][DD]  Sigma[row, row]
   T* so = sd + 64 * DD;                               // [64][DD]  Sigma[row, previous row of the current level]
