@@ -211,6 +211,29 @@ def test_full_size_closed_form(N, d, dtype, rtol):
     assert float((x2 - 2 * x).abs().max()) <= (1e-9 if dtype == torch.float64 else 1e-3)
 
 
+@pytest.mark.parametrize("N,d,dtype", [(2 ** 22, 8, torch.float32), (2 ** 20 + 7, 8, torch.float64),
+                                       (2 ** 20 + 65, 6, torch.float64), (2 ** 19 + 3, 7, torch.float64),
+                                       (2 ** 21 + 5, 4, torch.float64), (2 ** 21 + 1, 5, torch.float32)],
+                         ids=["c3_d8_f32_quads", "d8_f64_quads", "d6_f64_lds", "d7_f64_lds", "d4_f64_registers", "d5_f32_registers"])
+def test_inverse_blocks_full_size_identity(N, d, dtype):
+    """inverse_blocks at benchmark sizes (every form of the three-levels-per-launch pass: registers, LDS,
+    four lanes per row): the block diagonal of J Sigma is the identity -- it involves every diagonal and
+    every off-diagonal block of the result."""
+    Rs, Os, _, _, _ = _util.conditioned_system(N, d, dtype=dtype, device="cuda", seed=N % 1000)
+    Sd, So = cr.inverse_blocks(cr.decompose(Rs, Os))
+    worst, step = 0.0, 1 << 19
+    for a in range(0, N, step):                  # chunked: keeps the temporaries small
+        e = min(N, a + step)
+        res = Rs[a:e] @ Sd[a:e]
+        lo = max(a, 1)
+        res[lo - a:] += Os[lo - 1:e - 1] @ So[lo - 1:e - 1].transpose(1, 2)
+        hi = min(e, N - 1)
+        res[:hi - a] += Os[a:hi].transpose(1, 2) @ So[a:hi]
+        res -= torch.eye(d, dtype=dtype, device="cuda")
+        worst = max(worst, float(res.abs().max()))
+    assert worst < (1e-9 if dtype == torch.float64 else 2e-4), worst
+
+
 @pytest.mark.parametrize("n,d", [(2 ** 20, 4), (2 ** 20, 3), (2 ** 21, 4), (2 ** 20, 8)],
                          ids=["coherent_loads_d4", "acquire_d3", "acquire_two_per_cu_d4", "four_lanes_per_row_d8"])
 def test_folded_final_stage_never_reads_stale_records(n, d):

@@ -8,7 +8,10 @@ import _util
 import cyclic_gps.cyclic_reduction as cr
 
 for n, d, dtype in (((1 << 22) + 5, 4, torch.float64), (1 << 24, 4, torch.float64), ((1 << 23) + 77, 4, torch.float32),
-                    ((1 << 22) + 3, 2, torch.float64), ((1 << 21) + 1, 5, torch.float32)):
+                    ((1 << 22) + 3, 2, torch.float64), ((1 << 21) + 1, 5, torch.float32),
+                    # the large-block passes: four lanes per row (8 x 8), Sigma of the tile in LDS (fp64 d = 6, 7)
+                    (1 << 22, 8, torch.float32), ((1 << 21) + 129, 8, torch.float32), ((1 << 20) + 7, 8, torch.float64),
+                    ((1 << 20) + 65, 6, torch.float64), ((1 << 19) + 3, 7, torch.float64)):
     Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=n % 1000)
     dec = cr.decompose(Rs, Os)
     Sd, So = cr.inverse_blocks(dec)
