@@ -21,6 +21,40 @@ template <> struct Vec16<float>  { using type = float4;  static constexpr int N 
 __device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// ---- exchanges inside a DPP quad (four adjacent lanes sharing one block row) ------------------
+template <typename T> struct QuadOps;
+template <> struct QuadOps<float> {
+  template <int CTRL> static __device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+  }
+};
+template <> struct QuadOps<double> {
+  template <int CTRL> static __device__ __forceinline__ double dpp(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  }
+};
+// value of v held by lane `src` (a compile-time constant after unrolling) of this lane's quad
+template <typename T>
+__device__ __forceinline__ T quad_from(T v, int src) {
+  switch (src) {
+    case 0: return QuadOps<T>::template dpp<0x00>(v);
+    case 1: return QuadOps<T>::template dpp<0x55>(v);
+    case 2: return QuadOps<T>::template dpp<0xAA>(v);
+    default: return QuadOps<T>::template dpp<0xFF>(v);
+  }
+}
+// sum over the four lanes of the quad, in every lane
+template <typename T>
+__device__ __forceinline__ T quad_sum(T v) {
+  v += QuadOps<T>::template dpp<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += QuadOps<T>::template dpp<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  return v;
+}
+
+// threads per 128-row tile: one wave (16 quads, several rounds per level) at fp32, four waves at fp64
 // ---- reciprocal square root -------------------------------------------------
 // v_rsq_f64 is good to ~2^-23 relative; two Newton steps bring it to ~1 ulp.
 __device__ __forceinline__ double rsqrt_fast(double s) {

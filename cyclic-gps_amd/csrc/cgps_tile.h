@@ -242,6 +242,7 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 #endif
 
 #include "cgps_tile_mfma.h"
+#include "cgps_tile_quad.h"
 // A level goes to the 16-lanes-per-elimination form when one pass of the workgroup's waves covers
 // it (16 eliminations for 256 threads, 32 for 512): measured 0.9-1.2 us against 1.9-2.6 us for a
 // role-split pass, while two such passes are no faster than one role-split pass.
@@ -250,6 +251,9 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 // or 4 of them carried side by side per 16-lane group), role-split otherwise.
 #ifndef CGPS_MFMA_WIDE
 #define CGPS_MFMA_WIDE 1
+#endif
+#ifndef CGPS_TILE_QUAD
+#define CGPS_TILE_QUAD 1      // 8 x 8 blocks: four lanes per elimination in the in-LDS levels (0: role-split, for A/B builds)
 #endif
 template <typename T, int D, int NTHR, int MW = CGPS_MFMA_WIDE>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
@@ -264,10 +268,17 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
   const int role = wave & 3, grp = wave >> 2;
   const int K = n_real - 1;
   int levels = 0;
+  int opaque_tid = threadIdx.x;                 // (cgps_tile_quad.h: keeps the quad levels' addressing out of the caller's loops)
+  if constexpr (D == 8) asm volatile("" : "+v"(opaque_tid));
 #pragma unroll 1
   for (int s = 1; (s - 1) < K; s <<= 1, ++levels) {
     const int M = (K + 1) / s, h = s >> 1;
     const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
+    if constexpr (D == 8 && CGPS_TILE_QUAD) {
+      // four lanes per elimination (cgps_tile_quad.h), one barrier per level
+      tile_cr_level_quad<T, NTHR>(t, opaque_tid, K, M, s, pl, mah, fail);
+      continue;
+    }
     if constexpr (std::is_same<T, double>::value && D == 4) {
       // sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h); a level with more
       // eliminations than the workgroup has 16-lane groups carries 2 or 4 of them per group, side

@@ -12,6 +12,9 @@
 #ifndef DEVB_D
 #define DEVB_D 4          // block size of the tile_cr and timeline modes (-DDEVB_D=5 ...)
 #endif
+#ifndef DEVB_T
+#define DEVB_T double     // scalar type of the tile_cr mode (-DDEVB_T=float)
+#endif
 #include "cgps_tile.h"
 
 using namespace cgps;
@@ -161,7 +164,7 @@ static void run_mfma_probe() {
 // reduction itself is stamped by thread 0 between two barriers.
 template <int NTHR, int MW>
 __global__ __launch_bounds__(NTHR) void tilecr_bench_kernel(int n_real, int reps, long long* ticks, double* sums) {
-  using T = double;
+  using T = DEVB_T;
   constexpr int D = DEVB_D;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   StageSmem<T, D, 256, NTHR> sm(smem);
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(NTHR) void tilecr_bench_kernel(int n_real, int reps
 
 template <int NTHR, int MW>
 void run_tilecr(int grid, hipStream_t st) {
-  const size_t lds = stage_lds_bytes<double, DEVB_D>(256, NTHR);
+  const size_t lds = stage_lds_bytes<DEVB_T, DEVB_D>(256, NTHR);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&tilecr_bench_kernel<NTHR, MW>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long long* ticks;
