@@ -21,6 +21,14 @@ the wall time); solves/s is reported beside it.
 Extra objects in the JSON line: `roofline` (dominant kernel against the 8 TB/s
 HBM peak, timed with HIP events on the launch stream) and `cpu_baseline` (the
 oracle = torch-CPU restatement of the reference, timed on the host cores).
+
+Order of the run: the secondary measurements (`extras`) first, then the headline's W warm-up and K
+timed steps, then the CPU baseline.  A GPU that has been idle for a long time (a fresh box's first
+process) runs its first fraction of a second of kernels in a low power state: measured 77-81 us per
+step for the headline under `--steps 20 --warmup 5` as the first GPU work on a box, 73-74.5 us a few
+seconds after ANY other GPU work (a previous process, unrelated kernels).  With the secondary
+measurements first the headline does not depend on what ran on the box before; `--headline-first`
+restores the other order.
 """
 import argparse
 import ctypes
@@ -333,6 +341,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (Op B / config 3 / 2^24) numbers")
+    ap.add_argument("--headline-first", action="store_true",
+                    help="time the headline before the secondary measurements (on a long-idle GPU it then runs in the device's low power state)")
     ap.add_argument("--levelwise", action="store_true", help="time the one-launch-per-level form instead")
     ap.add_argument("--rows", type=int, default=0,
                     help="block rows of the WHOLE system (default: 2^20 on one GPU = config 2; 2^24 on several = config 4)")
@@ -406,6 +416,10 @@ def main():
                           _hip.ptr(out), _hip.ptr(info_), sp))
         return step_, info_, mahal_, logdet_
 
+    extras_early = None
+    if not sharded_mode and not args.no_extras and not args.headline_first:
+        extras_early = extra_measurements(dev)          # see the module docstring: order of the run
+        torch.cuda.empty_cache()
     if not sharded_mode:
         step, info, mahal_true, logdet_true = whole_system_step(rows)
     else:
@@ -415,6 +429,28 @@ def main():
 
         def step():
             plan.run(out)
+
+
+    def weak_point():
+        """Weak-scaling point (information only): 2^20 rows per GPU, one system of world * 2^20 rows."""
+        try:
+            nw = ROWS_PER_GPU * world
+            sz = 8 if dtype == torch.float64 else 4
+            Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(nw, d, dtype, dev, rank, world)
+            planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, nw, rank, world)
+            ew = _timed_steps(lambda: planw.run(out), args.steps, args.warmup, barrier)
+            tw = torch.tensor([ew], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            ew = float(tw.item()) / args.steps
+            rw = out.cpu()
+            return {"rows_total": nw, "ms_per_step": ew * 1e3, "GBps": algorithmic_bytes(nw, d, sz) / ew / 1e9,
+                    "logdet_rel_err": abs(float(rw[1]) - ldw) / abs(ldw)}
+        except Exception as e:
+            return {"error": repr(e)[:200]}
+
+    # several GPUs: the weak-scaling point first, for the same reason as the secondary measurements on one GPU
+    # (module docstring: a long-idle GPU's first kernels run in a low power state; it also brings RCCL up)
+    weak_early = weak_point() if (sharded_mode and world > 1 and not args.headline_first) else None
 
     # ---- timed region: W warm-up steps, then exactly K steps ----------------------------------
     elapsed = _timed_steps(step, args.steps, args.warmup, barrier)
@@ -475,20 +511,10 @@ def main():
                 scaling_extras["single_gpu_same_system"] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
         barrier()
-        try:      # weak-scaling point: 2^20 rows per GPU, one system of world * 2^20 rows
-            nw = ROWS_PER_GPU * world
-            Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(nw, d, dtype, dev, rank, world)
-            planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, nw, rank, world)
-            ew = _timed_steps(lambda: planw.run(out), args.steps, args.warmup, barrier)
-            tw = torch.tensor([ew], dtype=torch.float64, device=dev)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            ew = float(tw.item()) / args.steps
-            rw = out.cpu()
-            scaling_extras["weak_2^20_rows_per_gpu"] = {
-                "rows_total": nw, "ms_per_step": ew * 1e3, "GBps": algorithmic_bytes(nw, d, s) / ew / 1e9,
-                "logdet_rel_err": abs(float(rw[1]) - ldw) / abs(ldw)}
-        except Exception as e:
-            scaling_extras["weak_2^20_rows_per_gpu"] = {"error": repr(e)[:200]}
+        if weak_early is not None:
+            scaling_extras["weak_2^20_rows_per_gpu"] = weak_early
+        else:
+            scaling_extras["weak_2^20_rows_per_gpu"] = weak_point()
 
     if rank != 0:
         if use_dist:
@@ -546,7 +572,8 @@ def main():
     except Exception:
         pass
     if not sharded_mode and not args.no_extras:
-        line["extras"] = extra_measurements(dev)
+        line["extras"] = extras_early if extras_early is not None else extra_measurements(dev)
+        line["extras"]["order"] = "before the headline" if extras_early is not None else "after the headline"
     if not args.no_cpu_baseline and not sharded_mode:
         line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
     else:
