@@ -323,7 +323,6 @@ def _timed_steps(step, steps, warmup, barrier, region_events=None):
     for _ in range(warmup):
         step()
     barrier()
-    barrier()
     t0 = time.perf_counter()
     if region_events is not None:
         region_events[0].record()
