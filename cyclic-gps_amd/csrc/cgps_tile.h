@@ -255,6 +255,12 @@ __device__ __forceinline__ void eliminate_forward(T (&Rc)[D][D], T (&yc)[D], T (
 #ifndef CGPS_TILE_QUAD
 #define CGPS_TILE_QUAD 1      // 8 x 8 blocks: four lanes per elimination in the in-LDS levels (0: role-split, for A/B builds)
 #endif
+#ifndef CGPS_QUAD4_MIN_ELIM
+#define CGPS_QUAD4_MIN_ELIM(nthr) ((nthr) / 16)   // fp64 4 x 4: levels with more eliminations than this go to the quads, the rest to the matrix cores
+#endif
+#ifndef CGPS_TILE_QUAD4
+#define CGPS_TILE_QUAD4 1     // 4 x 4 blocks: the same for the wide levels (fp64) / all levels (fp32)
+#endif
 template <typename T, int D, int NTHR, int MW = CGPS_MFMA_WIDE>
 __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& pl, double& mah, bool& fail,
                                        long long* stamps = nullptr) {
@@ -269,15 +275,22 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
   const int K = n_real - 1;
   int levels = 0;
   int opaque_tid = threadIdx.x;                 // (cgps_tile_quad.h: keeps the quad levels' addressing out of the caller's loops)
-  if constexpr (D == 8) asm volatile("" : "+v"(opaque_tid));
+  if constexpr (D == 8 || D == 4) asm volatile("" : "+v"(opaque_tid));
 #pragma unroll 1
   for (int s = 1; (s - 1) < K; s <<= 1, ++levels) {
     const int M = (K + 1) / s, h = s >> 1;
     const int n_elim = (M + 1) / 2;             // upper bound on this level's eliminations
     if constexpr (D == 8 && CGPS_TILE_QUAD) {
       // four lanes per elimination (cgps_tile_quad.h), one barrier per level
-      tile_cr_level_quad<T, NTHR>(t, opaque_tid, K, M, s, pl, mah, fail);
+      tile_cr_level_quad<T, D, NTHR>(t, opaque_tid, K, M, s, pl, mah, fail);
       continue;
+    }
+    if constexpr (D == 4 && CGPS_TILE_QUAD4) {
+      // 4 x 4 blocks: the same for the levels too wide for the matrix cores (fp64), for every level (fp32)
+      if (!std::is_same<T, double>::value || n_elim > CGPS_QUAD4_MIN_ELIM(NTHR)) {
+        tile_cr_level_quad<T, D, NTHR>(t, opaque_tid, K, M, s, pl, mah, fail);
+        continue;
+      }
     }
     if constexpr (std::is_same<T, double>::value && D == 4) {
       // sixteen lanes per elimination on the matrix cores (cgps_tile_mfma.h); a level with more

@@ -9,13 +9,14 @@
 // lane's rows of G = Oc[l]^T D^-T and F = Oc[e] D^-T, one quad gather of G (parked G G^T and G x, new
 // coupling -F G^T) and one of F (right neighbour R_o -= F F^T, y_o -= F x).  Eliminations of a level
 // touch disjoint slots, a quad reads before it writes: ONE barrier per level.
-template <typename T>
+template <typename T, int D>
 struct QuadTile {
-  static constexpr int D = 8, DD = 64, RP = 2;
+  static_assert(D == 4 || D == 8, "a quad shares blocks whose rows split evenly over four lanes");
+  static constexpr int DD = D * D, RP = D / 4;             // RP: matrix rows per lane
   using LT = LdsTile<T, D>;
   using V = typename Vec16<T>::type;
-  static constexpr int VN = LT::VN, GO = 16 / VN;         // granules of a lane's two rows
-  static_assert(LT::SWZ, "8 x 8 blocks are stored with rotated granules");
+  static constexpr int VN = LT::VN, GO = RP * D / VN;      // granules of a lane's rows
+  static_assert(LT::SWZ && (RP * D) % VN == 0, "blocks stored with rotated granules, a lane's rows in whole granules");
 
   static __device__ __forceinline__ void load_rows(const T* base, int slot, int q, T (&own)[RP][D]) {
     const V* b = reinterpret_cast<const V*>(base + (size_t)slot * DD);
@@ -40,16 +41,16 @@ struct QuadTile {
       b[(q * GO + k) ^ kk] = v;
     }
   }
-  // the lane's two COLUMNS of a block: ownT[t][m] = block[m][2q + t]
+  // the lane's COLUMNS of a block: ownT[t][m] = block[m][RP q + t]
   static __device__ __forceinline__ void load_colpairs(const T* base, int slot, int q, T (&ownT)[RP][D]) {
     const T* b = base + (size_t)slot * DD;
     const int kk = LT::key(slot);
 #pragma unroll
     for (int m = 0; m < D; ++m) {
-      const int idx = m * D + 2 * q;
+      const int idx = m * D + RP * q;                 // RP consecutive elements, inside one granule (RP divides VN or RP == VN)
       const T* p = b + (((idx / VN) ^ kk) * VN + (idx % VN));
-      ownT[0][m] = p[0];
-      ownT[1][m] = p[1];
+#pragma unroll
+      for (int t = 0; t < RP; ++t) ownT[t][m] = p[t];
     }
   }
   static __device__ __forceinline__ void gather(const T (&own)[RP][D], T (&full)[D][D]) {
@@ -63,11 +64,11 @@ struct QuadTile {
 // tid: threadIdx.x as an OPAQUE value (see tile_cr): everything addressed through it is computed here, after
 // the streaming loop of the calling kernel, instead of being hoisted above that loop and kept alive through it
 // (two more 8-byte spills per streamed row in chunk_reduce_ml_kernel<float, 8>: +6 % on config 3).
-template <typename T, int NTHR>
-__device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, 8>& t, int tid, int K, int M, int s, PivotLog& pl,
+template <typename T, int D, int NTHR>
+__device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, D>& t, int tid, int K, int M, int s, PivotLog& pl,
                                                    double& mah, bool& fail) {
-  using QT = QuadTile<T>;
-  constexpr int D = 8, RP = 2, NQ = NTHR / 4;
+  using QT = QuadTile<T, D>;
+  constexpr int RP = QT::RP, NQ = NTHR / 4;
   const int q = tid & 3, Q = tid >> 2, h = s >> 1;
   const int n_elim = (M + 1) / 2;
 #pragma unroll 1
@@ -81,13 +82,13 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, 8>& t, int tid, in
       T A[RP][D], ye[RP];
       QT::load_rows(t.R, e, q, A);
 #pragma unroll
-      for (int a = 0; a < RP; ++a) ye[a] = t.y[e * D + 2 * q + a];
+      for (int a = 0; a < RP; ++a) ye[a] = t.y[e * D + RP * q + a];
       if ((s > 1) && (e + h < K)) {
         T P[RP][D];
         QT::load_rows(t.R, e + h, q, P);
 #pragma unroll
         for (int a = 0; a < RP; ++a) {
-          ye[a] -= t.y[(e + h) * D + 2 * q + a];
+          ye[a] -= t.y[(e + h) * D + RP * q + a];
 #pragma unroll
           for (int b = 0; b < D; ++b) A[a][b] -= P[a][b];
         }
@@ -148,13 +149,13 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, 8>& t, int tid, in
       T Ro[RP][D], yo[RP];
       QT::load_rows(t.R, o, q, Ro);
 #pragma unroll
-      for (int a = 0; a < RP; ++a) yo[a] = t.y[o * D + 2 * q + a];
+      for (int a = 0; a < RP; ++a) yo[a] = t.y[o * D + RP * q + a];
       if ((s > 1) && (o + h < K)) {
         T P[RP][D];
         QT::load_rows(t.R, o + h, q, P);
 #pragma unroll
         for (int a = 0; a < RP; ++a) {
-          yo[a] -= t.y[(o + h) * D + 2 * q + a];
+          yo[a] -= t.y[(o + h) * D + RP * q + a];
 #pragma unroll
           for (int b = 0; b < D; ++b) Ro[a][b] -= P[a][b];
         }
@@ -183,8 +184,8 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, 8>& t, int tid, in
       QT::store_rows(t.R, o, q, Ro);
 #pragma unroll
       for (int a = 0; a < RP; ++a) {
-        t.y[e * D + 2 * q + a] = wv[a];
-        t.y[o * D + 2 * q + a] = yo[a];
+        t.y[e * D + RP * q + a] = wv[a];
+        t.y[o * D + RP * q + a] = yo[a];
       }
     }
   }
