@@ -21,6 +21,9 @@
 
 namespace cgps {
 
+#ifndef CGPS_DECOMP_QUAD
+#define CGPS_DECOMP_QUAD 1     // 4 x 4 / 8 x 8 blocks: four lanes per elimination (0: role split, for A/B builds)
+#endif
 constexpr int DECL_LP = 8;
 constexpr int DECL_TS = 1 << DECL_LP;     // 256 rows per tile
 constexpr int DECL_NT = 256;             // four waves
@@ -147,6 +150,136 @@ __device__ __forceinline__ int tile_cr_factor(LdsTile<T, D>& t, int n0, bool kee
   return levels;
 }
 
+// The same with FOUR LANES PER ELIMINATION for 4 x 4 and 8 x 8 blocks (QuadTile, cgps_tile_quad.h): a DPP
+// quad takes an elimination, lane q owning matrix rows RP q .. RP q + RP - 1 of every block; the Cholesky
+// redundantly on the four lanes (lane 0 writes the dense factor D), the lane's rows of G and F solved, stored
+// and quad-gathered, the lane's rows of the parked G G^T, of the new coupling -F G^T and of the right
+// neighbour's R_o - F F^T.  Eliminations of a level touch disjoint slots and a quad reads before it writes:
+// one barrier per level instead of two per 64 eliminations, no role redundancy (and at 8 x 8 no spills).
+template <typename T, int D>
+__device__ __forceinline__ int tile_cr_factor_quad(LdsTile<T, D>& t, int n0, bool keep_last, int64_t row0,
+                                                   const DecompLevelsL& lv, T* __restrict__ Dp, T* __restrict__ Fp,
+                                                   T* __restrict__ Gp, int lvl_first, int* info, bool& fail) {
+  using QT = QuadTile<T, D>;
+  constexpr int DD = D * D, RP = QT::RP, NQ = DECL_NT / 4;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));                        // (see tile_cr: keeps this addressing out of the caller's code above)
+  const int q = tid & 3, Q = tid >> 2;
+  const int K = n0 - 1;
+  const int kl = keep_last ? 1 : 0;
+  int levels = 0;
+#pragma unroll 1
+  for (int s = 1, j = 0; j < lv.nlev && (keep_last ? (s - 1) < K : (n0 >> j) >= 1); s <<= 1, ++j, ++levels) {
+    const int M = n0 >> j, h = s >> 1;
+    const int n_elim = (M + 1) / 2;
+    const int64_t g0 = row0 >> (j + 1);
+#pragma unroll 1
+    for (int k0 = 0; k0 < n_elim; k0 += NQ) {
+      const int k = k0 + Q;
+      const int e = (2 * k + 1) * s - 1;
+      const bool act = (2 * k < M) && (e != K || !keep_last);
+      if (act) {
+        const bool has_o = (2 * k + 1 < M) || (keep_last && e < K);
+        const int o = (2 * k + 1 < M) ? e + s : K;
+        const int64_t ge = g0 + k;
+        T A[RP][D];
+        QT::load_rows(t.R, e, q, A);
+        if ((s > 1) && (e + h < K + 1 - kl)) {
+          T P[RP][D];
+          QT::load_rows(t.R, e + h, q, P);
+#pragma unroll
+          for (int a = 0; a < RP; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) A[a][b] -= P[a][b];
+        }
+        Chol<T, D> c;
+        {
+          T Af[D][D];
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int jj = 0; jj <= i; ++jj) Af[i][jj] = quad_from<T>(A[i % RP][jj], i / RP);
+          bool f = false;
+          chol_lower<T, D>(Af, c, f);
+          if (q == 0) {
+            if (f) {
+              fail = true;
+              report_fail(info, ((row0 + e + 1) << lvl_first) - 1);
+            }
+            T L[D][D];
+            chol_to_dense<T, D>(c, L);
+            store_block<T, D>(Dp + (lv.offD[j] + ge) * DD, L);
+          }
+        }
+        T G[RP][D], W[RP][D], Cn[RP][D], F[RP][D];
+        QT::load_colpairs(t.Oc, e - s + 1, q, G);
+#pragma unroll
+        for (int a = 0; a < RP; ++a) fwd_subst<T, D>(c, G[a]);
+        if (ge >= 1) QT::store_rows_global(Gp + (lv.offG[j] + ge - 1) * DD, q, G);
+        if (has_o) {
+          QT::load_rows(t.Oc, e + 1, q, F);
+#pragma unroll
+          for (int a = 0; a < RP; ++a) fwd_subst<T, D>(c, F[a]);
+          QT::store_rows_global(Fp + (lv.offF[j] + ge) * DD, q, F);
+        } else {
+#pragma unroll
+          for (int a = 0; a < RP; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) F[a][b] = T(0);
+        }
+        {
+          T Gf[D][D];
+          QT::gather(G, Gf);
+#pragma unroll
+          for (int a = 0; a < RP; ++a)
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) {
+              T sw = T(0), sc = T(0);
+#pragma unroll
+              for (int m = 0; m < D; ++m) {
+                sw = fmaT(G[a][m], Gf[jj][m], sw);
+                sc = fmaT(-F[a][m], Gf[jj][m], sc);
+              }
+              W[a][jj] = sw;
+              Cn[a][jj] = sc;
+            }
+        }
+        T Ro[RP][D];
+        if (has_o) {
+          QT::load_rows(t.R, o, q, Ro);
+          if ((s > 1) && (o + h < K + 1 - kl)) {
+            T P[RP][D];
+            QT::load_rows(t.R, o + h, q, P);
+#pragma unroll
+            for (int a = 0; a < RP; ++a)
+#pragma unroll
+              for (int b = 0; b < D; ++b) Ro[a][b] -= P[a][b];
+          }
+          T Ff[D][D];
+          QT::gather(F, Ff);
+#pragma unroll
+          for (int a = 0; a < RP; ++a)
+#pragma unroll
+            for (int jj = 0; jj < D; ++jj) {
+              T sr = Ro[a][jj];
+#pragma unroll
+              for (int m = 0; m < D; ++m) sr = fmaT(-F[a][m], Ff[jj][m], sr);
+              Ro[a][jj] = sr;
+            }
+        }
+        // everything this elimination reads has been read (the quad runs in lockstep): write
+        QT::store_rows(t.R, e, q, W);
+        if (has_o) {
+          QT::store_rows(t.Oc, e - s + 1, q, Cn);
+          QT::store_rows(t.R, o, q, Ro);
+        }
+      }
+    }
+    __syncthreads();                                  // the level's results are visible
+  }
+  return levels;
+}
+
 // One pass of the factorisation.  FROM_RECORDS = false: rows are the caller's Rs / Os (level 0).
 // FROM_RECORDS = true: rows are the previous pass's records (RecordLayout without the vector
 // parts): R = Rs[w] + dRa[w+1], coupling to the previous row Cs[w].
@@ -200,7 +333,11 @@ __global__ __launch_bounds__(DECL_NT) void decomp_lds_kernel(const T* __restrict
   }
   __syncthreads();
   bool fail = false;
-  const int levels = tile_cr_factor<T, D>(t, n0, keep_last, row0, lv, Dp, Fp, Gp, lvl_first, info, fail);
+  int levels;
+  if constexpr ((D == 4 || D == 8) && CGPS_DECOMP_QUAD)
+    levels = tile_cr_factor_quad<T, D>(t, n0, keep_last, row0, lv, Dp, Fp, Gp, lvl_first, info, fail);
+  else
+    levels = tile_cr_factor<T, D>(t, n0, keep_last, row0, lv, Dp, Fp, Gp, lvl_first, info, fail);
   if (tid == 0 && rec_out != nullptr) {
     // record: boundary row and its coupling to the previous tile's row (full tiles only), and what
     // the previous tile's row is owed (every tile)

@@ -53,6 +53,18 @@ struct QuadTile {
       for (int t = 0; t < RP; ++t) ownT[t][m] = p[t];
     }
   }
+  // the lane's rows of a contiguous block in global memory (the quad writes the block together)
+  static __device__ __forceinline__ void store_rows_global(T* __restrict__ blk, int q, const T (&own)[RP][D]) {
+    V* p = reinterpret_cast<V*>(blk) + q * GO;
+#pragma unroll
+    for (int k = 0; k < GO; ++k) {
+      V v;
+      T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+      for (int i = 0; i < VN; ++i) e[i] = own[(k * VN + i) / D][(k * VN + i) % D];
+      p[k] = v;
+    }
+  }
   static __device__ __forceinline__ void gather(const T (&own)[RP][D], T (&full)[D][D]) {
 #pragma unroll
     for (int i = 0; i < D; ++i)
