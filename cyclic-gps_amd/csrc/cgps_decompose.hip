@@ -10,7 +10,9 @@ using namespace cgps_host;
 
 namespace {
 // ---- fused (tiled) factorisation: cgps_decomp_tile.h (bulk passes) + cgps_decomp_lds.h (tail) ----
-constexpr int64_t DEC_SMALL_ROWS = 32768;   // at or below this many rows a pass is latency-bound
+// (8 x 8 blocks: the in-LDS passes, four lanes per elimination, beat the one-wave-per-tile register passes
+// already at 2^18 rows -- config 3: 1 490 -> 1 447 us; 4 x 4 fp64: no difference between 2^15 and 2^18)
+template <int D> constexpr int64_t dec_small_rows() { return D == 8 ? 262144 : 32768; }   // at or below this many rows a pass is latency-bound
 template <typename T, int D>
 int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
                        hipStream_t st) {
@@ -44,7 +46,7 @@ int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp,
   while (lvl < L.nlevels) {
     const int64_t rows = L.ms[lvl];
     const int remaining = L.nlevels - lvl;
-    if (rows <= DEC_SMALL_ROWS) {
+    if (rows <= dec_small_rows<D>()) {
       // latency-bound tail (or a small system): 256-row tiles in LDS, 8 levels per launch, four
       // waves per elimination (cgps_decomp_lds.h); one record per tile
       const int64_t g = (rows + cgps::DECL_TS - 1) / cgps::DECL_TS;
