@@ -286,14 +286,9 @@ __device__ __forceinline__ int tile_cr(LdsTile<T, D>& t, int n_real, PivotLog& p
       continue;
     }
     if constexpr (D == 4 && CGPS_TILE_QUAD4) {
-      // 4 x 4 blocks: the same for the levels too wide for the matrix cores (fp64), for every level (fp32);
-      // the role-split code below is then not even compiled into the kernel
+      // 4 x 4 blocks: the same for the levels too wide for the matrix cores (fp64), for every level (fp32)
       if (!std::is_same<T, double>::value || n_elim > CGPS_QUAD4_MIN_ELIM(NTHR)) {
         tile_cr_level_quad<T, D, NTHR>(t, opaque_tid, K, M, s, pl, mah, fail);
-        continue;
-      }
-      if constexpr (std::is_same<T, double>::value && MW == 1 && CGPS_QUAD4_MIN_ELIM(NTHR) <= NTHR / 16) {
-        tile_cr_level_mfma<NTHR, 1>(t, K, M, s, pl, mah, fail);
         continue;
       }
     }
