@@ -4,7 +4,7 @@ bidiagonal, so log|J| and the planted solution are known exactly -- tests/_util.
 Sizes are drawn around every switch point of the kernels (rows per lane 1 / 4 / 8 / 16, one or
 two workgroups per CU, record passes, decompose / solve pass structures) and uniformly in between.
 
-  python tools/fuzz_parity.py --seconds 120 [--seed 0]
+  python tools/fuzz_parity.py --seconds 120 [--seed 0] [--d 4 8]
 """
 import argparse
 import os
@@ -42,12 +42,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--d", type=int, nargs="*", default=None, help="block sizes to draw from (default: 1..8, 4 weighted)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     t0 = time.time()
     cases = worst64 = worst32 = 0
     while time.time() - t0 < a.seconds:
-        d = rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 7, 8])
+        d = rng.choice(a.d if a.d else [1, 2, 3, 4, 4, 4, 5, 6, 7, 8])
         dtype = rng.choice([torch.float64, torch.float64, torch.float32])
         n = draw_n(rng, (1 << 21) + 300 if d <= 4 else (1 << 19) + 300)
         Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=rng.randrange(1 << 30))
