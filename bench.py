@@ -41,7 +41,23 @@ import time
 # the GPU boxes; set before HIP initialises in case a launcher dropped it)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
+import socket      # noqa: E402
+import subprocess  # noqa: E402
+import threading   # noqa: E402
+
+# torch is imported by the RANK processes only (_load_torch): the launcher of a several-GPU run
+# (`python bench.py --gpus N` with no WORLD_SIZE in the environment) starts N fresh children and must
+# not create a GPU context -- or even load torch -- itself.
+torch = None
+
+
+def _load_torch():
+    global torch
+    if torch is None:
+        import torch as _torch
+        torch = _torch
+    return torch
+
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests")):
@@ -51,10 +67,10 @@ for p in (ROOT, os.path.join(ROOT, "cyclic-gps_amd"), os.path.join(ROOT, "tests"
 HBM_PEAK_GBPS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:36
 ROWS_PER_GPU = 1 << 20         # config 2 (and the weak-scaling point)
 ROWS_CONFIG4 = 1 << 24         # config 4: ONE system, sharded over the GPUs
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"
-KERNEL_STATS_FILE = "r02_kernel_stats_headline.csv"
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"
+PMC_TRAFFIC_SHARD_FILE = "r03_pmc_traffic_shards.json"     # per-shard figures, keyed by rows per rank
+KERNEL_STATS_FILE = "r03_kernel_stats_headline.csv"
 D = 4
-DTYPE = torch.float64
 
 
 def algorithmic_bytes(n, d, s):
@@ -87,35 +103,53 @@ def _mkl_version():
     return "unknown"
 
 
-def cpu_baseline(n, d, dtype, reps=3):
+def cpu_baseline(n, d, dtype, reps=3, sample_note=None, threads=None):
     """The oracle (port of the reference's op sequence) on the host cores, same workload
-    (all cores and one thread; nproc, CPU model, torch / MKL versions)."""
+    (Op A = mahal_and_det and Op B = decompose + solve, all cores and one
+    thread; nproc, CPU model, torch / MKL versions)."""
     from oracle import cr_oracle
     Rs, Os, b, _, _ = make_system(n, d, dtype, "cpu")
+    if threads:
+        torch.set_num_threads(threads)
     cores = torch.get_num_threads()
 
-    def best_of(k):
+    def best_of(fn, k):
         best = float("inf")
         for _ in range(k):
             t0 = time.perf_counter()
-            cr_oracle.mahal_and_det(Rs, Os, b)
+            fn()
             best = min(best, time.perf_counter() - t0)
         return best
-    cr_oracle.mahal_and_det(Rs[: n // 8], Os[: n // 8 - 1], b[: n // 8])       # warm-up
-    best = best_of(reps)
+
+    def op_a():
+        cr_oracle.mahal_and_det(Rs, Os, b)
+
+    def op_b():
+        cr_oracle.solve(cr_oracle.decompose(Rs, Os), b)
+    m = max(n // 8, 2)
+    cr_oracle.mahal_and_det(Rs[:m], Os[:m - 1], b[:m])       # warm-up
+    best = best_of(op_a, reps)
+    best_b = best_of(op_b, 2)
     torch.set_num_threads(1)
     try:
-        cr_oracle.mahal_and_det(Rs[: n // 8], Os[: n // 8 - 1], b[: n // 8])
-        best1 = best_of(2)
+        cr_oracle.mahal_and_det(Rs[:m], Os[:m - 1], b[:m])
+        best1 = best_of(op_a, 2)
+        best1_b = best_of(op_b, 1)
     finally:
         torch.set_num_threads(cores)
-    nbytes = algorithmic_bytes(n, d, Rs.element_size())
+    s = Rs.element_size()
+    nbytes = algorithmic_bytes(n, d, s)
+    nbytes_b = (5.0 * n * d * d + 3.0 * n * d * d + 2.0 * n * d) * s       # B_dec + B_solve of SURVEY.md 8(d)
     return {"value": 1.0 / best, "unit": "solves/s", "seconds": best, "GBps": nbytes / best / 1e9, "cores": cores,
             "kind": "port",
             "one_thread": {"value": 1.0 / best1, "seconds": best1, "GBps": nbytes / best1 / 1e9, "cores": 1},
+            "opB_decompose_plus_solve": {"value": 1.0 / best_b, "unit": "factor+solves/s", "seconds": best_b,
+                                         "GBps": nbytes_b / best_b / 1e9, "cores": cores,
+                                         "one_thread": {"value": 1.0 / best1_b, "seconds": best1_b, "cores": 1}},
             "nproc": os.cpu_count(), "cpu_model": _cpu_model(), "torch": torch.__version__, "mkl": _mkl_version(),
-            "sample": "full workload N=%d d=%d %s: min of %d runs on %d threads and min of 2 runs on 1 thread "
-                      "(torch.set_num_threads), each after a 1/8-size warm-up"
+            "sample": (sample_note + ": " if sample_note else "full workload ") +
+                      "N=%d d=%d %s; Op A (mahal_and_det): min of %d runs on %d threads and min of 2 runs on 1 thread "
+                      "(torch.set_num_threads), each after a 1/8-size warm-up; Op B (decompose + solve): min of 2 runs / 1 run"
                       % (n, d, str(dtype).replace("torch.", ""), reps, cores)}
 
 
@@ -251,6 +285,43 @@ def extra_measurements(dev):
         out["opA_two_systems_in_flight_N2^20_d4_f64"] = two_systems_in_flight(dev, 1 << 20, 4, torch.float64, 200)
     except Exception as e:
         out["opA_two_systems_in_flight_N2^20_d4_f64"] = {"error": repr(e)[:200]}
+    # the per-rank part of the 8-GPU run of config 4: ONE 2^21-row shard through the sharded code path
+    # (cgps_shard_reduce + cgps_finish_records, everything but the collective), and the same with 2 sub-shards
+    try:
+        from cyclic_gps import sharded
+        n21 = 1 << 21
+        Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(n21, 4, torch.float64, dev, 0, 1)
+        o2 = torch.zeros(2, dtype=torch.float64, device=dev)
+        res = {}
+        for S in (1, 2):
+            planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, n21, 0, 1, sub_shards=S)
+            res["sub_shards_%d_us" % S] = _time_cuda(lambda: planw.run(o2), 100, warm=20) * 1e6
+            res["sub_shards_%d_logdet_rel_err" % S] = abs(float(o2[1]) - ldw) / abs(ldw)
+            del planw
+        res["whole_system_same_rows_us"] = _time_cuda(lambda: cr.mahal_and_det(Rw, Ow, bw), 100, warm=20) * 1e6
+        out["c4_per_rank_shard_2^21_d4_f64"] = res
+        del Rw, Ow, bw
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["c4_per_rank_shard_2^21_d4_f64"] = {"error": repr(e)[:200]}
+    # fp64 d = 5 (the LEG rank of config 5) at 2^20 rows, and solve with eight right-hand sides at config 2
+    try:
+        Rs, Os, b, x_true, logdet_true = make_system(1 << 20, 5, torch.float64, dev)
+        t5 = _time_cuda(lambda: cr.mahal_and_det(Rs, Os, b), 20, warm=5)
+        out["d5_N2^20_f64"] = {"mahal_and_det_us": t5 * 1e6, "frac_of_8TBps": algorithmic_bytes(1 << 20, 5, 8) / t5 / 1e9 / HBM_PEAK_GBPS,
+                               "logdet_rel_err": abs(float(cr.mahal_and_det(Rs, Os, b)[1]) - logdet_true) / abs(logdet_true)}
+        del Rs, Os, b, x_true
+        Rs, Os, b, x_true, _ = make_system(1 << 20, 4, torch.float64, dev)
+        dec = cr.decompose(Rs, Os)
+        Y = (b[:, :, None] * torch.arange(1, 9, dtype=b.dtype, device=dev)).contiguous()
+        t8 = _time_cuda(lambda: cr.solve(dec, Y), 10)
+        X = cr.solve(dec, Y)
+        out["solve_8rhs_N2^20_d4_f64"] = {"solve_us": t8 * 1e6, "us_per_column": t8 * 1e6 / 8,
+                                          "max_abs_err": float((X[:, :, 2] - 3.0 * x_true).abs().max())}
+        del Rs, Os, b, x_true, dec, Y, X
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["d5_and_8rhs"] = {"error": repr(e)[:200]}
     cr.CHECK_POSITIVE_DEFINITE = True
     # BASELINE config 5: LEG log-likelihood + posterior mean on the CO2-shaped series (N=502, rank 5),
     # parameters and expected values from the fixture recorded from the reference
@@ -340,7 +411,100 @@ def _file_sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-def main():
+def kernel_source_sha16():
+    """One digest over every file the headline translation unit is built from (csrc/cgps_mahal.hip, every
+    header under csrc/ and include/cgps.h): profiles/*pmc_traffic*.json records it, and a traffic figure
+    measured on other sources is reported as stale."""
+    import hashlib
+    csrc = os.path.join(ROOT, "cyclic-gps_amd", "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(".h")) + ["cgps_mahal.hip"]
+    h = hashlib.sha256()
+    for f in names:
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cgps.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---- several GPUs: the launcher --------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, child_cmd=None, timeout_s=None):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start N fresh rank processes of this
+    script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set), relay rank 0's JSON line and
+    return the first non-zero exit status (0 when every rank succeeded).  This process makes NO GPU call and
+    never loads torch; it never re-execs.  A rank that dies takes the others down after a grace period (each
+    by its own PID), so a failed collective cannot leave the job hanging.
+    child_cmd: the command of a rank (tests pass a stand-in); default: this script with the same arguments."""
+    if child_cmd is None:
+        child_cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("CGPS_BENCH_TIMEOUT", "1500"))
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CGPS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(child_cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True))
+    lines = [[] for _ in range(n)]
+
+    def pump(r):
+        for ln in procs[r].stdout:
+            lines[r].append(ln)
+            if r != 0:                       # other ranks print nothing on stdout; whatever they do goes to stderr
+                sys.stderr.write("[rank %d] %s" % (r, ln))
+    threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(n)]
+    for t in threads:
+        t.start()
+    t0 = time.monotonic()
+    failed_at = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.monotonic()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = now
+        if (failed_at is not None and now - failed_at > 15.0) or now - t0 > timeout_s:
+            for p in procs:                  # exact PIDs of the children this process started
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.1)
+    for p in procs:
+        p.wait()
+    for t in threads:
+        t.join(timeout=5.0)
+    codes = [p.returncode for p in procs]
+    # the status of a rank that failed by itself comes first; ranks this launcher ended have negative codes
+    rc = next((c for c in codes if c > 0), next((c for c in codes if c != 0), 0))
+    out = [ln for ln in lines[0] if ln.lstrip().startswith("{")]
+    for ln in lines[0]:
+        if not ln.lstrip().startswith("{"):
+            sys.stderr.write("[rank 0] " + ln)
+    if out:
+        sys.stdout.write(out[-1] if out[-1].endswith("\n") else out[-1] + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+    if rc != 0:
+        sys.stderr.write("bench.py launcher: rank exit codes %s\n" % codes)
+    return rc if rc > 0 else (1 if rc != 0 else 0)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -348,20 +512,32 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (Op B / config 3 / 2^24) numbers")
     ap.add_argument("--headline-first", action="store_true",
-                    help="time the headline before the secondary measurements (on a long-idle GPU it then runs in the device's low power state)")
+                    help="time ONLY the warm protocol's order reversed: headline before the secondary measurements")
     ap.add_argument("--levelwise", action="store_true", help="time the one-launch-per-level form instead")
     ap.add_argument("--rows", type=int, default=0,
                     help="block rows of the WHOLE system (default: 2^20 on one GPU = config 2; 2^24 on several = config 4)")
     ap.add_argument("--d", type=int, default=D)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    args = ap.parse_args()
+    ap.add_argument("--sub-shards", type=int, default=0,
+                    help="several GPUs: sub-shards per rank (0 = the library's default for the shard size)")
+    ap.add_argument("--weak-point", action="store_true", help="several GPUs: also time 2^20 rows per GPU (extras)")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank_main(args)
+
+
+def rank_main(args):
+    _load_torch()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # CGPS_BENCH_REHEARSAL_GLOO=1: several ranks on ONE GPU over gloo -- exercises the multi-process
     # flow (shard kernels with a left neighbour, the collective, the finish kernel) on a 1-GPU box;
@@ -377,18 +553,21 @@ def main():
     from cyclic_gps import _hip
     lib = _hip.lib()
 
-    # CGPS_BENCH_FORCE_SHARDED=1 runs the sharded code path with a single rank (rehearsal on a 1-GPU box)
+    # CGPS_BENCH_FORCE_SHARDED=1 runs the sharded code path with a single rank (the per-rank part of the
+    # several-GPU run, measured on a 1-GPU box)
     force_sharded = os.environ.get("CGPS_BENCH_FORCE_SHARDED") == "1"
     sharded_mode = world > 1 or force_sharded
-    use_dist = world > 1 or (force_sharded and "RANK" in os.environ)
+    use_dist = world > 1
     if sharded_mode:
-        import torch.distributed as dist
         from cyclic_gps import sharded
-        if use_dist:
-            if rehearsal:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=dev)
+    if use_dist:
+        import datetime
+        import torch.distributed as dist
+        to = datetime.timedelta(seconds=float(os.environ.get("CGPS_BENCH_COLLECTIVE_TIMEOUT", "300")))
+        if rehearsal:
+            dist.init_process_group("gloo", timeout=to)
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=to)
     # the workload: config 2 on one GPU; config 4 (ONE 2^24-row system, strong scaling) on several
     n_total = args.rows if args.rows > 0 else (ROWS_CONFIG4 if world > 1 else ROWS_PER_GPU)
     if sharded_mode:
@@ -430,46 +609,47 @@ def main():
                 _hip.check(rc)
         return step_, info_, mahal_, logdet_
 
-    extras_early = None
-    if not sharded_mode and not args.no_extras and not args.headline_first:
-        extras_early = extra_measurements(dev)          # see the module docstring: order of the run
-        torch.cuda.empty_cache()
+    plan = None
     if not sharded_mode:
         step, info, mahal_true, logdet_true = whole_system_step(rows)
     else:
         Rs, Os, b, O_left, mahal_true, logdet_true = sharded.make_sharded_system(n_total, d, dtype, dev, rank, world)
-        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world)
+        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world,
+                                          sub_shards=(args.sub_shards or None))
         info = plan.ops.info
 
         def step():
             plan.run(out)
 
+    # ---- one GPU: the COLD protocol first.  The same W + K steps as the first GPU work of this process (on a
+    # fresh box: of the box).  A GPU that has idled runs its first fraction of a second in a low power state and
+    # a system that is streamed for the first time finds nothing of itself in the memory-side cache: this is
+    # what a caller whose operands change every call sees.  Reported in extras.headline_cold; the headline
+    # `value` below is the warm protocol (after the secondary measurements), as in rounds 1 and 2. -----------
+    headline_cold = None
+    s_el = 8 if dtype == torch.float64 else 4
+    if not sharded_mode and not args.headline_first:
+        e_cold = _timed_steps(step, args.steps, args.warmup, barrier) / args.steps
+        headline_cold = {"ms_per_step": e_cold * 1e3, "GBps": algorithmic_bytes(rows, d, s_el) / e_cold / 1e9,
+                         "frac_of_8TBps": algorithmic_bytes(rows, d, s_el) / e_cold / 1e9 / HBM_PEAK_GBPS,
+                         "note": "the same %d warm-up + %d timed steps as the FIRST GPU work of the process, before the "
+                                 "secondary measurements; `value` is the same protocol after them" % (args.warmup, args.steps)}
+    extras_early = None
+    if not sharded_mode and not args.no_extras and not args.headline_first:
+        extras_early = extra_measurements(dev)          # see the module docstring: order of the run
+        torch.cuda.empty_cache()
 
-    def weak_point():
-        """Weak-scaling point (information only): 2^20 rows per GPU, one system of world * 2^20 rows."""
-        try:
-            nw = ROWS_PER_GPU * world
-            sz = 8 if dtype == torch.float64 else 4
-            Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(nw, d, dtype, dev, rank, world)
-            planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, nw, rank, world)
-            ew = _timed_steps(lambda: planw.run(out), args.steps, args.warmup, barrier)
-            tw = torch.tensor([ew], dtype=torch.float64, device=dev)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            ew = float(tw.item()) / args.steps
-            rw = out.cpu()
-            return {"rows_total": nw, "ms_per_step": ew * 1e3, "GBps": algorithmic_bytes(nw, d, sz) / ew / 1e9,
-                    "logdet_rel_err": abs(float(rw[1]) - ldw) / abs(ldw)}
-        except Exception as e:
-            return {"error": repr(e)[:200]}
-
-    # several GPUs: the weak-scaling point first, for the same reason as the secondary measurements on one GPU
-    # (module docstring: a long-idle GPU's first kernels run in a low power state; it also brings RCCL up)
-    weak_early = weak_point() if (sharded_mode and world > 1 and not args.headline_first) else None
+    # several GPUs: bring the GPU out of its idle power state (and RCCL up) with untimed steps of the SAME plan
+    # -- a fixed count on every rank, so the ranks stay in step -- before the W warm-up and the K timed steps
+    if sharded_mode:
+        for _ in range(int(os.environ.get("CGPS_BENCH_PREWARM_STEPS", "2000"))):
+            step()
+        barrier()
 
     # ---- timed region: W warm-up steps, then exactly K steps ----------------------------------
     region_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     elapsed = _timed_steps(step, args.steps, args.warmup, barrier, region_ev)
-    region_avg_s = region_ev[0].elapsed_time(region_ev[1]) / max(args.steps - 1, 1) / 1e3     # launch-to-launch time inside the timed region (steps 2..K)
+    region_avg_s = region_ev[0].elapsed_time(region_ev[1]) / max(args.steps - 1, 1) / 1e3     # launch period inside the timed region (steps 2..K)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -490,15 +670,11 @@ def main():
     barrier()
     elapsed_with_events = time.perf_counter() - t1
     kernel_ms = sorted(a.elapsed_time(c) for a, c in evs)
-    bracketed_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-    # Two upper bounds of the dominant kernel's duration: events around each single launch (kernel + the two
-    # event packets: a bubble of ~1-2 us between back-to-back kernels), and -- when a step IS one launch of
-    # that kernel (the record stages run inside it) -- events around the K timed steps divided by K (kernel +
-    # launch-to-launch gap).  The tighter one is reported; rocprofv3's own begin/end stamps of the same command
-    # are in profiles/ (kernel_avg_us_rocprofv3).
-    one_launch_per_step = ((not args.levelwise) and (not sharded_mode) and rows <= (1 << 22) and d == 4
-                           and dtype == torch.float64 and os.environ.get("CGPS_NO_FOLD") != "1")
-    kernel_avg_s = min(bracketed_avg_s, region_avg_s) if one_launch_per_step else bracketed_avg_s
+    # ONE estimator for roofline.achieved: HIP events around each launch of the dominant kernel (an upper
+    # bound of its duration: kernel + the two event packets); min <= avg by construction.  The launch period
+    # inside the timed region (events around steps 2..K, divided by K-1) and rocprofv3's own figure from the
+    # committed profile of this command are side fields.
+    kernel_avg_s = sum(kernel_ms) / len(kernel_ms) / 1e3
 
     # ---- correctness of what was timed (closed form) ---------------------------------------
     res = out.cpu()
@@ -508,41 +684,41 @@ def main():
     assert int(info.item()) == 0, "library reported a non-positive-definite block"
     assert rel_ld < tol and rel_m < tol * 10, ("result mismatch", rel_ld, rel_m)
 
-    s = 8 if dtype == torch.float64 else 4
+    s = s_el
     t_step = elapsed / args.steps
     b_total = algorithmic_bytes(n_total, d, s)
-    b_kernel = algorithmic_bytes(rows, d, s)     # what ONE launch of the dominant kernel streams (one shard)
+    b_kernel = algorithmic_bytes(rows, d, s)     # what the dominant kernel streams per step on this rank (one shard)
 
-    # ---- several GPUs: the single-GPU time of the SAME system (speed-up) and the weak-scaling point,
-    # outside the timed region ----------------------------------------------------------------
+    # ---- several GPUs: the single-GPU time of the SAME system (speed-up), outside the timed region ------
     scaling_extras = None
     if sharded_mode and world > 1:
-        scaling_extras = {}
+        scaling_extras = {"sub_shards_per_rank": plan.sub_shards, "records_per_rank": plan.records_per_rank}
+        if args.weak_point:
+            scaling_extras["weak_2^20_rows_per_gpu"] = _weak_point(args, dev, dtype, d, rank, world, out, barrier)
         del plan, Rs, Os, b
         torch.cuda.empty_cache()
-        k1 = max(3, min(10, args.steps))
-        if rank == 0:
-            try:
-                step1, info1, m1, ld1 = whole_system_step(n_total)
-                e1 = _timed_steps(step1, k1, 2, torch.cuda.synchronize) / k1
-                r1 = out.cpu()
-                scaling_extras["single_gpu_same_system"] = {
-                    "rows": n_total, "ms_per_step": e1 * 1e3, "GBps": b_total / e1 / 1e9,
-                    "logdet_rel_err": abs(float(r1[1]) - ld1) / abs(ld1), "steps": k1}
-                scaling_extras["speedup_vs_single_gpu"] = e1 / t_step
-                del step1
-            except Exception as e:
-                scaling_extras["single_gpu_same_system"] = {"error": repr(e)[:200]}
-            torch.cuda.empty_cache()
         barrier()
-        if weak_early is not None:
-            scaling_extras["weak_2^20_rows_per_gpu"] = weak_early
-        else:
-            scaling_extras["weak_2^20_rows_per_gpu"] = weak_point()
+        dist.destroy_process_group()             # no collective after this point: the other ranks are done
+        use_dist = False
+        if rank != 0:
+            return
+        k1 = max(3, min(10, args.steps))
+        try:
+            step1, info1, m1, ld1 = whole_system_step(n_total)
+            e1 = _timed_steps(step1, k1, 2, torch.cuda.synchronize) / k1
+            r1 = out.cpu()
+            scaling_extras["single_gpu_same_system"] = {
+                "rows": n_total, "ms_per_step": e1 * 1e3, "GBps": b_total / e1 / 1e9,
+                "logdet_rel_err": abs(float(r1[1]) - ld1) / abs(ld1), "steps": k1}
+            scaling_extras["speedup_vs_single_gpu"] = e1 / t_step
+            del step1
+        except Exception as e:
+            scaling_extras["single_gpu_same_system"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+    elif sharded_mode:
+        scaling_extras = {"sub_shards_per_rank": plan.sub_shards, "records_per_rank": plan.records_per_rank}
 
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
         return
     cfgname = "config 4" if n_total == ROWS_CONFIG4 else ("config 2" if n_total == ROWS_PER_GPU else "custom size")
     line = {
@@ -551,12 +727,12 @@ def main():
         "value": b_total / t_step / 1e9, "unit": "GB/s",
         "solves_per_s": 1.0 / t_step,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
-        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "none", "vs_baseline": None,
         "dtype": "f64" if dtype == torch.float64 else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE %s: mahal_and_det on ONE SPD block-tridiagonal system, N=%d block rows (%d per "
                                "GPU), d=%d, conditioned bidiagonal-factor generator seed 1234" % (cfgname, n_total, rows, d),
                    "rows_total": n_total, "rows_per_gpu": rows, "d": d, "algorithmic_bytes": b_total,
-                   "parallelism": "time-axis shards x%d, one all-gather of boundary blocks" % world if world > 1
+                   "parallelism": "time-axis shards x%d, one all-gather of boundary records" % world if world > 1
                    else "single GPU",
                    "algo": "levelwise" if args.levelwise else "tile-fused"},
         "roofline_frac_whole_op": b_total / t_step / 1e9 / (HBM_PEAK_GBPS * world),
@@ -564,8 +740,9 @@ def main():
                      "unit": "GB/s", "frac": b_kernel / kernel_avg_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                      "kernel": "first-pass reduction kernel (streams Rs, Os, x once)",
                      "kernel_avg_us": kernel_avg_s * 1e6, "kernel_min_us": kernel_ms[0] * 1e3,
-                     "kernel_avg_us_events_around_each_launch": bracketed_avg_s * 1e6,
-                     "kernel_avg_us_events_around_the_timed_region": region_avg_s * 1e6 if one_launch_per_step else None,
+                     "kernel_max_us": kernel_ms[-1] * 1e3,
+                     "estimator": "HIP events around each launch of the dominant kernel, on its stream, K launches",
+                     "launch_period_us_in_timed_region": region_avg_s * 1e6 if args.steps >= 2 else None,
                      "algorithmic_bytes_per_launch": b_kernel,
                      "ms_per_step_with_event_hooks": elapsed_with_events / args.steps * 1e3},
         "check": {"logdet_rel_err": rel_ld, "mahal_rel_err": rel_m},
@@ -578,35 +755,72 @@ def main():
     # The file names the kernel sources it was measured on; when they have changed since, the figure
     # is reported as stale instead of being passed off as current.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-        if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise and world == 1:
-            line["roofline"]["traffic"] = pmc["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
-            sha = pmc.get("kernel_source_sha16")
-            if sha is not None:
-                cur = {f: _file_sha16(os.path.join(ROOT, "cyclic-gps_amd", "csrc", f)) for f in sha}
-                line["roofline"]["traffic_stale"] = cur != sha
+        rl = line["roofline"]
+        if rows == 1 << 20 and d == 4 and dtype == torch.float64 and not args.levelwise and not sharded_mode:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+            rl["traffic"] = pmc["hbm_bytes_per_launch"]
+            rl["traffic_source"] = "profiles/" + PMC_TRAFFIC_FILE
+            rl["traffic_stale"] = pmc.get("kernel_source_sha16") != kernel_source_sha16()
             # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats
-            # summary of this command (HIP events around a launch also see its dispatch latency)
+            # summary of this command
             import csv
             prof = "profiles/" + KERNEL_STATS_FILE
             for r in csv.DictReader(open(os.path.join(ROOT, prof))):
-                if "chunk_reduce_kernel" in r["Name"]:
-                    line["roofline"]["kernel_avg_us_rocprofv3"] = float(r["AverageNs"]) / 1e3
-                    line["roofline"]["kernel_avg_us_rocprofv3_source"] = prof
+                if "chunk_reduce" in r["Name"] or "stream_reduce" in r["Name"]:
+                    rl["kernel_avg_us_rocprofv3"] = float(r["AverageNs"]) / 1e3
+                    rl["kernel_avg_us_rocprofv3_source"] = prof
                     break
-    except Exception:
-        pass
+        elif sharded_mode and d == 4 and dtype == torch.float64:
+            # per-shard figure: the shard kernels of one rank, measured on one GPU with the sharded code path
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_SHARD_FILE)))
+            ent = pmc.get("rows_per_rank", {}).get(str(rows))
+            if ent is not None:
+                rl["traffic"] = ent["hbm_bytes_per_step"]
+                rl["traffic_source"] = "profiles/" + PMC_TRAFFIC_SHARD_FILE + " (one rank's shard kernels, measured on one GPU)"
+                rl["traffic_stale"] = pmc.get("kernel_source_sha16") != kernel_source_sha16()
+            else:
+                rl["traffic_note"] = "no PMC pass committed for %d rows per rank (see %s)" % (rows, PMC_TRAFFIC_SHARD_FILE)
+    except Exception as e:
+        line["roofline"]["traffic_note"] = "no committed PMC figure: " + repr(e)[:120]
     if not sharded_mode and not args.no_extras:
         line["extras"] = extras_early if extras_early is not None else extra_measurements(dev)
-        line["extras"]["order"] = "before the headline" if extras_early is not None else "after the headline"
-    if not args.no_cpu_baseline and not sharded_mode:
-        line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
+        line["extras"]["order"] = ("cold W+K steps, secondary measurements, then the headline" if extras_early is not None
+                                   else "headline first")
+    if headline_cold is not None:
+        line.setdefault("extras", {})["headline_cold"] = headline_cold
+    if not args.no_cpu_baseline:
+        if world > 1 or sharded_mode:
+            # bounded sample (the full 2^24-row system is ~25 s per run on the host cores): the 2^20-row system of
+            # the same generator -- the oracle's time is linear in the rows, its GB/s is what carries over
+            threads = None
+            if os.environ.get("OMP_NUM_THREADS") == "1" and "TORCHELASTIC_RUN_ID" in os.environ:
+                threads = max(1, (os.cpu_count() or 2) // 2)     # torchrun pins ranks to one thread: undo it for the baseline
+            line["cpu_baseline"] = cpu_baseline(ROWS_PER_GPU, d, dtype, sample_note="bounded sample, 1/%d of the rows of the "
+                                                "timed system (the oracle is linear in the rows)" % max(1, n_total // ROWS_PER_GPU),
+                                                threads=threads)
+        else:
+            line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
     else:
         line["cpu_baseline"] = None
     print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+
+
+def _weak_point(args, dev, dtype, d, rank, world, out, barrier):
+    """Weak-scaling point (information only, --weak-point): 2^20 rows per GPU, one system of world * 2^20 rows.
+    No exception is swallowed around a collective: a rank that fails here ends, and the launcher ends the job."""
+    import torch.distributed as dist
+    from cyclic_gps import sharded
+    nw = ROWS_PER_GPU * world
+    sz = 8 if dtype == torch.float64 else 4
+    Rw, Ow, bw, Olw, mw, ldw = sharded.make_sharded_system(nw, d, dtype, dev, rank, world)
+    planw = sharded.ShardedMahalLogdet(Rw, Ow, bw, Olw, nw, rank, world)
+    ew = _timed_steps(lambda: planw.run(out), args.steps, args.warmup, barrier)
+    tw = torch.tensor([ew], dtype=torch.float64, device=dev)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    ew = float(tw.item()) / args.steps
+    rw = out.cpu()
+    return {"rows_total": nw, "ms_per_step": ew * 1e3, "GBps": algorithmic_bytes(nw, d, sz) / ew / 1e9,
+            "logdet_rel_err": abs(float(rw[1]) - ldw) / abs(ldw)}
 
 
 if __name__ == "__main__":

@@ -68,35 +68,80 @@ class HipShardOps:
             _hip.stream_ptr()))
 
 
+def _default_gather(group):
+    def gather(send, recv):
+        dist.all_gather_into_tensor(recv, send, group=group)      # the ONE collective
+    return gather
+
+
 class ShardedMahalLogdet:
     """mahal_and_det of ONE block-tridiagonal system split over the ranks of `group`.
 
     Rs [n_loc,d,d], Os [n_loc-1,d,d] (couplings inside the shard), x [n_loc,d] are this rank's
     rows; O_left [d,d] = J[first local row, last row of the previous rank] (None on rank 0).
     run() returns a 2-element float64 tensor {x^T J^-1 x, log|J|}, identical on every rank.
-    `ops` is the pair of device steps (default: the HIP library); tests inject a dense-algebra
-    stand-in to exercise the collective plumbing on CPU/gloo."""
 
-    def __init__(self, Rs, Os, x, O_left, n_total, rank, world, group=None, ops=None):
+    sub_shards = S > 1 cuts the rank's rows into S consecutive sub-shards, each reduced to its own
+    record by its own cgps_shard_reduce on its own HIP stream (the serial tail of one overlaps the
+    streaming of the next), and the ONE all-gather then carries S records per rank; the finish kernel
+    takes the world * S records in order.  Default: one record per rank -- a shard of more than one
+    round of the chip is already reduced by ONE launch whose workgroups overlap the in-LDS reduction
+    of a tile with the streaming of the next (csrc/cgps_tile_stream.h).
+    `ops` is the pair of device steps (default: the HIP library); tests inject a dense-algebra
+    stand-in to exercise the collective plumbing on CPU/gloo.  `gather(send, recv)` replaces the
+    collective (tests play the ranks one after the other on one GPU)."""
+
+    def __init__(self, Rs, Os, x, O_left, n_total, rank, world, group=None, ops=None, sub_shards=None, gather=None):
         self.Rs, self.Os, self.x, self.O_left = Rs, Os, x, O_left
         self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
         self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
-        self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
-        self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
+        S = max(1, min(int(sub_shards or 1), max(1, n_total // world)))
+        self.sub_shards = self.records_per_rank = S
         dev = Rs.device
-        self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
-        self.recv = torch.zeros(world * self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.subs = []
+        for s_ in range(S):
+            lo, hi = shard_bounds(self.n_loc, S, s_)
+            o = ops if ops is not None else HipShardOps(hi - lo, self.d, Rs.dtype, dev)
+            if ops is None and S > 1:
+                o.ws = o.ws.clone()              # one workspace (and so one set of arrival counters) per launch in flight
+            self.subs.append(dict(ops=o, Rs=Rs[lo:hi], Os=Os[lo:hi - 1], x=x[lo:hi],
+                                  O_left=(O_left if lo == 0 else Os[lo - 1]),
+                                  stream=(torch.cuda.Stream(device=dev) if (S > 1 and dev.type == "cuda") else None)))
+        self.ops = self.subs[0]["ops"]
+        self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
+        self.send = torch.zeros(S * self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(world * S * self.msg_bytes, dtype=torch.uint8, device=dev)
         self.out = torch.empty(2, dtype=torch.float64, device=dev)
+        self.gather = gather if gather is not None else _default_gather(group)
+
+    def reduce_to_send(self):
+        """Step 1: this rank's sub-shards -> records in the send buffer (no communication)."""
+        mb = self.msg_bytes
+        if self.sub_shards == 1 or self.subs[0]["stream"] is None:
+            for i, sub in enumerate(self.subs):
+                sub["ops"].shard_reduce(sub["Rs"], sub["Os"], sub["x"], sub["O_left"], self.send[i * mb:(i + 1) * mb],
+                                        self.rec_bytes)
+            return
+        cur = torch.cuda.current_stream()
+        for i, sub in enumerate(self.subs):
+            st = sub["stream"]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                sub["ops"].shard_reduce(sub["Rs"], sub["Os"], sub["x"], sub["O_left"], self.send[i * mb:(i + 1) * mb],
+                                        self.rec_bytes)
+        for sub in self.subs:
+            cur.wait_stream(sub["stream"])
 
     def run(self, out=None):
         out = self.out if out is None else out
-        self.ops.shard_reduce(self.Rs, self.Os, self.x, self.O_left, self.send, self.rec_bytes)
+        self.reduce_to_send()
         if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)      # the ONE collective
+            self.gather(self.send, self.recv)
             src = self.recv
         else:
             src = self.send
-        self.ops.finish(src, self.world, self.rec_bytes, self.msg_bytes, self.n_loc, self.n_total, out)
+        P = self.world * self.sub_shards
+        self.ops.finish(src, P, self.rec_bytes, self.msg_bytes, max(1, self.n_total // P), self.n_total, out)
         return out
 
 
@@ -148,9 +193,10 @@ class ShardedSolve:
       3. every rank solves its interior rows (all but its last one) with the two separator values
          moved to the right-hand side -- a local decompose + solve, no further communication.
     The interior factor is kept between calls (Rs / Os are fixed, y changes).  `ops` / `solve_ops`
-    are the device steps (defaults: the HIP library); tests inject CPU stand-ins under gloo."""
+    are the device steps (defaults: the HIP library); tests inject CPU stand-ins under gloo.
+    `gather(send, recv)` replaces the collective (tests play the ranks in sequence on one GPU)."""
 
-    def __init__(self, Rs, Os, O_left, n_total, rank, world, group=None, ops=None, solve_ops=None):
+    def __init__(self, Rs, Os, O_left, n_total, rank, world, group=None, ops=None, solve_ops=None, gather=None):
         self.Rs, self.Os, self.O_left = Rs, Os, O_left
         self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
         self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
@@ -161,13 +207,19 @@ class ShardedSolve:
         self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
         self.recv = torch.zeros(world * self.msg_bytes, dtype=torch.uint8, device=dev)
         self._interior = None
+        self.gather = gather if gather is not None else _default_gather(group)
+
+    def reduce_to_send(self, y):
+        """Step 1: this rank's shard, with the right-hand side, -> its record in the send buffer."""
+        self.ops.shard_reduce(self.Rs, self.Os, y, self.O_left, self.send, self.rec_bytes)
+        return self.send
 
     def run(self, y):
         n, d = self.n_loc, self.d
         y = y.contiguous()
-        self.ops.shard_reduce(self.Rs, self.Os, y, self.O_left, self.send, self.rec_bytes)
+        self.reduce_to_send(y)
         if self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)      # the ONE collective
+            self.gather(self.send, self.recv)
             src = self.recv
         else:
             src = self.send

@@ -177,8 +177,10 @@ int cgps_leg_intercast(const void* ts, int64_t n, const void* target_ts, int64_t
  * records 16-byte aligned), so both can be read in place from
  * the receive buffer of an all-gather of [record | partial] messages (record_out and
  * partial_out of cgps_shard_reduce may point straight into the send buffer; partial_out must
- * be 8-byte aligned).  P <= 1024 (256 for d = 8).  Built for every block size whose 256-row tile fits the LDS:
- * fp64 d <= 5 and fp32 d <= 8 (CGPS_ERR_UNSUPPORTED otherwise). */
+ * be 8-byte aligned).  P <= 1024 (256 for fp32 d = 8 and fp64 d = 7; 64 for fp64 d = 6 and d = 8).  Built for every block size
+ * 1 <= d <= 8 in both precisions.  A rank may send several records (its rows cut into consecutive sub-shards,
+ * each reduced by its own cgps_shard_reduce with O_left = the coupling to the previous sub-shard's last row):
+ * cgps_finish_records simply takes all of them in row order. */
 int cgps_record_elems(int d, int dtype, int64_t* elems);
 int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void* O_left, int64_t n_loc, int d,
                       int dtype, void* ws, size_t ws_bytes, void* record_out, double* partial_out, void* stream);

@@ -142,7 +142,8 @@ def test_hip_operand_assembly_matches_reference(name):
     Rs, Os = leg._peg_precision_hip(ts, m.G)
     np.testing.assert_allclose(Rs.cpu().numpy(), g["Sig_Rs"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(Os.cpu().numpy(), g["Sig_Os"], rtol=1e-9, atol=1e-11)
-    # the dispatcher takes the kernel when no gradient is wanted and torch ops when one is
+    # the dispatcher takes the forward kernel either way; with a gradient wanted it is an autograd function whose
+    # backward is the adjoint kernel (cgps_peg_precision_adjoint)
     Rs2, _ = leg.peg_precision(ts, m.G)
     assert Rs2.grad_fn is None and torch.equal(Rs2, Rs)
     Gg = m.G.clone().requires_grad_(True)

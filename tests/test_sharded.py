@@ -64,7 +64,7 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, n_total, d, q):
+def _gloo_worker(rank, world, port, n_total, d, q, sub_shards=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -73,7 +73,9 @@ def _gloo_worker(rank, world, port, n_total, d, q):
         lo, hi = sharded.shard_bounds(n_total, world, rank)
         assert Rs.shape[0] == hi - lo and Os.shape[0] == hi - lo - 1
         assert (O_left is None) == (rank == 0)
-        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world, ops=SD.DenseShardOps(d))
+        plan = sharded.ShardedMahalLogdet(Rs, Os, b, O_left, n_total, rank, world, ops=SD.DenseShardOps(d),
+                                          sub_shards=sub_shards)
+        assert plan.records_per_rank == min(sub_shards, n_total // world)
         out = plan.run().clone()
         # every rank must hold the same result
         outs = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
@@ -97,11 +99,14 @@ def _gloo_worker(rank, world, port, n_total, d, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total,d", [(2, 257, 3), (3, 100, 2), (2, 2, 4)])
-def test_collective_path_under_gloo(world, n_total, d):
+@pytest.mark.parametrize("world,n_total,d,sub_shards", [(2, 257, 3, 1), (3, 100, 2, 1), (2, 2, 4, 1), (2, 257, 3, 4),
+                                                         (3, 10, 2, 2), (2, 5, 2, 3)])
+def test_collective_path_under_gloo(world, n_total, d, sub_shards):
+    """One all-gather of the ranks' records (sub_shards of them per rank: the sub-shard layout), then the
+    finish over world * sub_shards records; ragged sub-shards and sub-shards of one row included."""
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    mp.spawn(_gloo_worker, args=(world, _free_port(), n_total, d, q), nprocs=world, join=True)
+    mp.spawn(_gloo_worker, args=(world, _free_port(), n_total, d, q, sub_shards), nprocs=world, join=True)
     res = q.get()
     for o in res["outs"]:
         np.testing.assert_allclose(o, res["outs"][0], rtol=0, atol=0)
@@ -184,6 +189,24 @@ def test_config4_as_eight_shards_on_one_gpu():
     np.testing.assert_allclose(got, [mahal_true, logdet], rtol=1e-10)
     m, ld = cr.mahal_and_det(Rs, Os, b)                     # the same system as ONE shard
     np.testing.assert_allclose(got, [float(m), float(ld)], rtol=1e-12)
+    # the sub-shard layout: every rank's 2^21 rows as S sub-shards on S streams, S records per rank in the
+    # all-gather buffer, ONE finish over the 8 S records (ShardedMahalLogdet with the ranks played in sequence)
+    for S in (2, 4):
+        plans, sends = [], []
+        for r, (sR, sO, sx, Ol) in enumerate(_split(Rs, Os, b, bounds)):
+            pl = sharded.ShardedMahalLogdet(sR, sO, sx, None if Ol is None else Ol.contiguous(), n, r, parts, sub_shards=S,
+                                            gather=lambda send, recv: recv.copy_(torch.cat(sends)))
+            assert pl.records_per_rank == S
+            pl.reduce_to_send()
+            torch.cuda.synchronize()
+            sends.append(pl.send.clone())
+            plans.append(pl)
+        for r in (0, parts - 1):
+            got_s = plans[r].run().cpu().numpy()
+            assert int(plans[r].ops.info.item()) == 0
+            np.testing.assert_allclose(got_s, [mahal_true, logdet], rtol=1e-10)
+            np.testing.assert_allclose(got_s, [float(m), float(ld)], rtol=1e-12)
+        del plans, sends
 
 
 # ---- sharded solve (ShardedSolve: records -> separator values -> local interior solves) -------------------
@@ -218,40 +241,29 @@ def test_sharded_solve_under_gloo(world, n_total, d):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,d,parts,dtype", [(5000, 4, 4, torch.float64), (70001, 3, 5, torch.float64),
-                                             (2 ** 20, 4, 8, torch.float64), (40000, 8, 3, torch.float32)])
+                                             (2 ** 20, 4, 8, torch.float64), (40000, 8, 3, torch.float32),
+                                             (9, 4, 5, torch.float64), (5, 2, 5, torch.float64)])
 def test_sharded_solve_on_one_gpu(n, d, parts, dtype):
-    """The same three steps with the HIP kernels, the ranks played one after the other on one GPU:
-    shard records (cgps_shard_reduce with the right-hand side) -> boundary system -> separator values
-    -> every shard's interior through decompose + solve; against the planted solution."""
-    import cyclic_gps.cyclic_reduction as cr
+    """ShardedSolve.run itself with world > 1 and the HIP kernels, the ranks played one after the other on
+    one GPU through an injected gather (the left-coupling correction, the kept interior factor, shards of
+    two rows -- an interior with no coupling block -- and of one row included); against the planted solution."""
     dev = torch.device("cuda")
     Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=3 + n)
     bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
-    rec_bytes, msg_bytes = sharded.message_layout(d, dtype)
-    recv = torch.zeros(parts * msg_bytes, dtype=torch.uint8, device=dev)
-    shards = _split(Rs, Os, b, bounds)
-    for r, (sR, sO, sx, Ol) in enumerate(shards):
-        ops = sharded.HipShardOps(sR.shape[0], d, dtype, dev)
-        ops.shard_reduce(sR.contiguous(), sO.contiguous(), sx.contiguous(), None if Ol is None else Ol.contiguous(),
-                         recv[r * msg_bytes:(r + 1) * msg_bytes], rec_bytes)
-    Rb, Ob, yb = sharded.boundary_system(recv, parts, rec_bytes, msg_bytes, d, dtype)
-    x_sep = cr.solve(cr.decompose(Rb, Ob), yb)
+    sends = []
+    plans = [sharded.ShardedSolve(sR.contiguous(), sO.contiguous(), None if Ol is None else Ol.contiguous(), n, r, parts,
+                                  gather=lambda send, recv: recv.copy_(torch.cat(sends)))
+             for r, (sR, sO, sx, Ol) in enumerate(_split(Rs, Os, b, bounds))]
     tol = 1e-9 if dtype == torch.float64 else 2e-3
-    for r, (sR, sO, sx, Ol) in enumerate(shards):
-        plan = sharded.ShardedSolve(sR.contiguous(), sO.contiguous(), None if Ol is None else Ol.contiguous(), n, r, 1)
-        # world = 1 inside the plan would rebuild a one-row boundary system: drive step 3 directly instead
-        nl = sR.shape[0]
-        x = torch.empty_like(sx)
-        x[-1] = x_sep[r]
-        if nl > 1:
-            rhs = sx[:-1].clone()
-            if r > 0:
-                rhs[0] -= Ol @ x_sep[r - 1]
-            rhs[-1] -= sO[nl - 2].T @ x_sep[r]
-            x[:-1] = cr.solve(cr.decompose(sR[:-1].contiguous(), sO[:nl - 2].contiguous()), rhs)
-        lo, hi = bounds[r]
-        assert float((x - x_true[lo:hi]).abs().max()) <= tol, (r, float((x - x_true[lo:hi]).abs().max()))
-        del plan
+    for scale in (1.0, -2.0):                       # second pass: the interior factor is reused, the solve is linear
+        y = scale * b
+        sends.clear()
+        for r, (lo, hi) in enumerate(bounds):
+            sends.append(plans[r].reduce_to_send(y[lo:hi].contiguous()).clone())
+        for r, (lo, hi) in enumerate(bounds):
+            x = plans[r].run(y[lo:hi].contiguous())
+            err = float((x - scale * x_true[lo:hi]).abs().max())
+            assert err <= tol * abs(scale), (r, scale, err)
 
 
 @pytest.mark.gpu
