@@ -78,4 +78,9 @@ int cgps_finish_records(const void* records, size_t record_stride_bytes, const d
   });
 }
 
+int cgps_reset_counters(void* stream) {
+  if (cgps::fold_reset_counters((hipStream_t)stream) != hipSuccess) return check_launch("cgps_reset_counters");
+  return CGPS_OK;
+}
+
 }  // extern "C"

@@ -461,7 +461,7 @@ __device__ __forceinline__ typename Vec16<T>::type load16_coh(const T* p) {
 // Arrival counters of the folded final stage.  They live in the library's own device data (zero
 // when the code object is loaded, touched by nothing else) rather than in the caller's
 // workspace, whose contents are arbitrary before a call and which other entry points use as
-// scratch.  A counter is incremented with a wrapping atomic (atomicInc: old >= limit ? 0 : old + 1),
+// scratch (one copy per translation unit that launches the fused pipeline: cgps_mahal.hip).  A counter is incremented with a wrapping atomic (atomicInc: old >= limit ? 0 : old + 1),
 // so the arrival that completes the count also puts it back to 0: no per-call memset, no reset
 // store, and a replayed graph launch finds it clean.  The host maps each workspace it has seen to
 // one slot (fold_slot_for): two launches may be in flight at the same time only with different
@@ -1190,9 +1190,6 @@ static __global__ __launch_bounds__(256) void sum_partials4_kernel(const double*
 // ---- stage 1 for large blocks: one block row over four lanes --------------------------------------
 #include "cgps_tile_ml.h"
 
-// ---- systems of more than one round of the chip: persistent launch, streaming and reducing waves ----
-#include "cgps_tile_stream.h"
-
 // ---- host side ------------------------------------------------------------------------------
 // does the 256-row LDS tile of the record stages fit the 160 KB of LDS?  (fp64 d <= 5, fp32 d <= 8)
 template <typename T, int D> constexpr bool tile_fits_256() {
@@ -1204,30 +1201,6 @@ template <typename T, int D> constexpr bool tile_fits_256() {
 // decompose has its own, narrower condition: decomp_tile_supported().
 template <typename T, int D> constexpr bool tile_supported() { return D >= 1 && D <= 8; }
 template <typename T, int D> constexpr bool decomp_tile_supported() { return tile_fits_256<T, D>(); }
-// the persistent form of cgps_tile_stream.h (two tile buffers in LDS): 4 x 4 fp64 blocks
-template <typename T, int D> constexpr bool stream_supported() { return std::is_same<T, double>::value && D == 4; }
-inline bool stream_enabled() {              // CGPS_NO_STREAM=1: rounds of chunk_reduce_kernel as before (A/B timing)
-  static const bool on = [] { const char* e = getenv("CGPS_NO_STREAM"); return !(e && e[0] == '1'); }();
-  return on;
-}
-inline int64_t stream_min_tiles() {         // CGPS_STREAM_MIN_TILES=<n>: the persistent form from n + 1 tiles on (tests: small systems)
-  static const int64_t v = [] { const char* e = getenv("CGPS_STREAM_MIN_TILES"); return e ? (int64_t)atoll(e) : STAGE1_SMALL_TILES; }();
-  return v;
-}
-inline int stream_cus() {                   // compute units of the current device (one persistent workgroup each)
-  static const int forced = [] { const char* e = getenv("CGPS_STREAM_CUS"); return e ? atoi(e) : 0; }();   // tests: few workgroups, many tiles each
-  if (forced > 0) return forced;
-  static int cus[64] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) dev = 0;
-  if (cus[dev] == 0) {
-    int c = 0;
-    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
-    cus[dev] = c > 0 ? c : 256;
-  }
-  return cus[dev];
-}
 template <typename T, int D> struct TileCfg {
   // BIG blocks (fp64 d = 6, 7, 8): a 256-row tile does not fit the LDS; tiles of 64 / 128 kept rows
   static constexpr bool BIG = !tile_fits_256<T, D>();
@@ -1297,13 +1270,6 @@ void tile_set_attributes() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 1, Cfg::NT1, Cfg::NT1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
   }
-  if constexpr (stream_supported<T, D>()) {
-    const int ldss = (int)stream_lds_bytes<T, D, Cfg::NT1>();
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_reduce_kernel<T, D, Cfg::C, Cfg::NT1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, ldss);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_reduce_kernel<T, D, Cfg::C, Cfg::NT1, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, ldss);
-  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&record_reduce_kernel<T, D, Cfg::NTILE3, Cfg::NT3, true>),
@@ -1311,20 +1277,49 @@ void tile_set_attributes() {
   });
 }
 
-// slot of the arrival counter that belongs to this (device, workspace); -1 when all slots are taken
-// (the caller then runs the final stage as a second launch)
-inline int fold_slot_for(const void* ws) {
+// Slot of the arrival counters that belongs to this (device, workspace).  The counters are device data of THIS
+// translation unit (static __device__ above), so the map is too (internal linkage, not `inline`).  A slot's
+// counters are zero whenever no launch that uses it is in flight (the arrival that completes a count wraps it to
+// zero), so a slot can be handed to another workspace: when all FOLD_SLOTS slots are taken, the slot whose last
+// launch is the longest ago is reused -- a caller whose workspace address changes from call to call (a C program that
+// allocates per call, torch after empty_cache(), graph-private pools) keeps the one-launch path.  What this
+// assumes: fewer than FOLD_SLOTS launches with different workspaces in flight at the same time.
+// cgps_reset_counters() zeroes the counters of the current device (after a launch that died half-way).
+static int fold_slot_for(const void* ws) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, int> slots;
+  static std::pair<int, const void*> owner[FOLD_SLOTS];
+  static unsigned long long last_use[FOLD_SLOTS];
+  static unsigned long long tick = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
+  const std::pair<int, const void*> key{dev, ws};
   std::lock_guard<std::mutex> lock(mu);
-  auto it = slots.find({dev, ws});
-  if (it != slots.end()) return it->second;
-  if ((int)slots.size() >= FOLD_SLOTS) return -1;
-  const int s = (int)slots.size();
-  slots.emplace(std::make_pair(dev, ws), s);
+  auto it = slots.find(key);
+  int s;
+  if (it != slots.end()) {
+    s = it->second;
+  } else if ((int)slots.size() < FOLD_SLOTS) {
+    s = (int)slots.size();
+    slots.emplace(key, s);
+    owner[s] = key;
+  } else {
+    s = 0;
+    for (int k = 1; k < FOLD_SLOTS; ++k)
+      if (last_use[k] < last_use[s]) s = k;
+    slots.erase(owner[s]);
+    slots.emplace(key, s);
+    owner[s] = key;
+  }
+  last_use[s] = ++tick;
   return s;
+}
+// zero every arrival counter of the current device, on `st` (cgps_reset_counters)
+static hipError_t fold_reset_counters(hipStream_t st) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_fold_counter));
+  if (e != hipSuccess) return e;
+  return hipMemsetAsync(p, 0, sizeof(unsigned int) * FOLD_SLOTS * (1 + FOLD_MAX_GROUPS), st);
 }
 inline bool fold_final_enabled() {          // CGPS_NO_FOLD=1: two launches as before (cross-check / A-B timing)
   static const bool on = [] { const char* e = getenv("CGPS_NO_FOLD"); return !(e && e[0] == '1'); }();
@@ -1354,7 +1349,6 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   T* recB = recA + (size_t)(tiles_cap + 2) * RL::STRIDE;
   const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1), lds3 = stage_lds_bytes<T, D>(Cfg::NTILE3, Cfg::NT3);
   tile_set_attributes<T, D>();
-  int64_t rec_count = tiles, rec_rows = rows_per_tile;      // records stage 1 leaves, rows behind each
   if (ev_start) (void)hipEventRecord(ev_start, st);
   if constexpr (Cfg::LPR > 1) {
     const int slot = (tiles > 1 && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
@@ -1380,26 +1374,6 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     }
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
                        dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
-  } else if (stream_supported<T, D>() && (N + Cfg::ROWS1 - 1) / Cfg::ROWS1 > stream_min_tiles() && stream_enabled()) {
-    // more than one round of the chip: ONE persistent launch, one workgroup per CU walking its own run of
-    // consecutive rows tile by tile, the in-LDS reduction of a tile underneath the streaming of the next
-    // (cgps_tile_stream.h); one record per workgroup, so the record stages are always inside the launch
-    if constexpr (stream_supported<T, D>()) {
-      const StreamPlan sp = stream_plan(N, Cfg::C, Cfg::NT1, stream_cus());
-      const int slot = (sp.grid > 1 && sp.grid <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
-      const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
-      const size_t ldss = stream_lds_bytes<T, D, Cfg::NT1>();
-      if (slot >= 0) {
-        hipLaunchKernelGGL((stream_reduce_kernel<T, D, Cfg::C, Cfg::NT1, true>), dim3((unsigned)sp.grid), dim3(2 * Cfg::NT1),
-                           ldss, st, Rs, Os, x, N, Oleft, recA, partial, fa, sp.rows_per_wg, sp.tile_rows);
-        if (ev_stop) (void)hipEventRecord(ev_stop, st);
-        return 0;
-      }
-      hipLaunchKernelGGL((stream_reduce_kernel<T, D, Cfg::C, Cfg::NT1, false>), dim3((unsigned)sp.grid), dim3(2 * Cfg::NT1),
-                         ldss, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{}, sp.rows_per_wg, sp.tile_rows);
-      rec_count = sp.grid;
-      rec_rows = sp.rows_per_wg;
-    }
   } else if (csel != Cfg::C) {
     // small systems (fewer rows per lane, at most one workgroup per CU): the same one-launch form --
     // no faster on the GPU's clock than two launches (measured 2^14 .. 2^19 rows), but one node in a
@@ -1456,7 +1430,7 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     }
   }
   if (ev_stop) (void)hipEventRecord(ev_stop, st);
-  int64_t n = rec_count, npart = rec_count, rows_per_record = rec_rows;
+  int64_t n = tiles, npart = tiles, rows_per_record = rows_per_tile;
   T *rin = recA, *rout = recB;
   // a shard is reduced all the way to ONE record; the whole system stops as soon as the final
   // workgroup can take what is left

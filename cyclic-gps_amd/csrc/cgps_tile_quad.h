@@ -76,12 +76,9 @@ struct QuadTile {
 // tid: threadIdx.x as an OPAQUE value (see tile_cr): everything addressed through it is computed here, after
 // the streaming loop of the calling kernel, instead of being hoisted above that loop and kept alive through it
 // (two more 8-byte spills per streamed row in chunk_reduce_ml_kernel<float, 8>: +6 % on config 3).
-// SYNC = false, base: the wave-local form of cgps_tile_stream.h -- ONE wave (NTHR = 64) reduces the rows
-// [base, base + K + 1) of the tile as a system of its own (K, M, s count from `base`), no workgroup barrier:
-// a wave's LDS instructions execute in order, and a quad reads before it writes.
-template <typename T, int D, int NTHR, bool SYNC = true>
+template <typename T, int D, int NTHR>
 __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, D>& t, int tid, int K, int M, int s, PivotLog& pl,
-                                                   double& mah, bool& fail, int base = 0) {
+                                                   double& mah, bool& fail) {
   using QT = QuadTile<T, D>;
   constexpr int RP = QT::RP, NQ = NTHR / 4;
   const int q = tid & 3, Q = tid >> 2, h = s >> 1;
@@ -89,18 +86,16 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, D>& t, int tid, in
 #pragma unroll 1
   for (int k0 = 0; k0 < n_elim; k0 += NQ) {
     const int k = k0 + Q;
-    const int e_loc = (2 * k + 1) * s - 1;
-    const bool act = (2 * k < M) && (e_loc != K);
+    const int e = (2 * k + 1) * s - 1;
+    const bool act = (2 * k < M) && (e != K);
     if (act) {
-      const int K_abs = K + base;
-      const int e = e_loc + base;
-      const int o = (2 * k + 1 < M) ? e + s : K_abs;
+      const int o = (2 * k + 1 < M) ? e + s : K;
       // the eliminated row (less what is parked for it), factored on all four lanes
       T A[RP][D], ye[RP];
       QT::load_rows(t.R, e, q, A);
 #pragma unroll
       for (int a = 0; a < RP; ++a) ye[a] = t.y[e * D + RP * q + a];
-      if ((s > 1) && (e + h < K_abs)) {
+      if ((s > 1) && (e + h < K)) {
         T P[RP][D];
         QT::load_rows(t.R, e + h, q, P);
 #pragma unroll
@@ -167,7 +162,7 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, D>& t, int tid, in
       QT::load_rows(t.R, o, q, Ro);
 #pragma unroll
       for (int a = 0; a < RP; ++a) yo[a] = t.y[o * D + RP * q + a];
-      if ((s > 1) && (o + h < K_abs)) {
+      if ((s > 1) && (o + h < K)) {
         T P[RP][D];
         QT::load_rows(t.R, o + h, q, P);
 #pragma unroll
@@ -206,5 +201,5 @@ __device__ __forceinline__ void tile_cr_level_quad(LdsTile<T, D>& t, int tid, in
       }
     }
   }
-  if constexpr (SYNC) __syncthreads();              // the level's results are visible
+  __syncthreads();                                  // the level's results are visible
 }

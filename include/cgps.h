@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CGPS_VERSION 210
+#define CGPS_VERSION 300
 
 enum { CGPS_F32 = 0, CGPS_F64 = 1 };
 
@@ -187,6 +187,13 @@ int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void*
 int cgps_finish_records(const void* records, size_t record_stride_bytes, const double* partials,
                         size_t partial_stride_bytes, int64_t P, int64_t rows_per_shard, int64_t N_total, int d,
                         int dtype, double* out2, int* info, void* stream);
+
+/* The one-launch forms of cgps_mahal_logdet / cgps_shard_reduce hand records from workgroup to workgroup inside the
+ * launch through arrival counters in the library's own device memory.  Every completed launch leaves them at zero;
+ * a launch that did NOT complete (a GPU fault in another kernel of the process, a killed context that was revived)
+ * can leave a count half-way.  cgps_reset_counters enqueues a memset of all of them on `stream` (current device).
+ * Call it with no library call in flight on that device.  Never needed in normal operation. */
+int cgps_reset_counters(void* stream);
 
 /* Measurement hook (bench.py): the next cgps_mahal_logdet call on this host thread
  * records `start` right before and `stop` right after its dominant kernel (the one

@@ -5,6 +5,8 @@
 Tolerances: north_star asks for 1e-5 relative (fp64 log-det / solve) and 1e-4
 (fp32 posterior mean); the fp64 checks here are far tighter (1e-9 .. 1e-11).
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -267,6 +269,56 @@ def test_folded_final_stage_never_reads_stale_records(n, d):
             assert abs(ld - logdet) <= 1e-10 * abs(logdet)
             assert abs(ld - ld_ref) <= 1e-11 * abs(ld_ref) and abs(m - m_ref) <= 1e-9 * abs(m_ref)
         assert (m, ld) == first[k], (k, m, ld, first[k])
+
+
+@pytest.mark.parametrize("n,d", [(2 ** 20, 4), (2 ** 21, 4), (2 ** 19 + 77, 5)])
+def test_in_launch_hand_off_under_uneven_load(n, d):
+    """The same alternation of DIFFERENT systems through one workspace while a second stream keeps the memory system
+    busy with unrelated traffic in bursts (copies of 512 MB, uneven load: the hand-off forms that drop the acquire are
+    the ones that go stale only under load -- micro-architecture guide, inter-workgroup visibility), every result
+    checked bit for bit against what the same system gave on the idle chip.  Run ONCE: a check, not a stress loop.
+    Also: cgps_reset_counters() between two calls leaves the one-launch path working, and more workspaces than the
+    library has counter slots keep it working (the slot of the least recently used workspace is reused)."""
+    from cyclic_gps import _hip
+    systems = []
+    cr.CHECK_POSITIVE_DEFINITE = False
+    try:
+        for seed in (21, 22, 23):
+            Rs, Os, b, x_true, logdet = _util.conditioned_system(n - 4096 * (seed - 21), d, seed=seed, device="cuda")
+            m, ld = cr.mahal_and_det(Rs, Os, b)
+            torch.cuda.synchronize()
+            assert abs(float(ld) - logdet) <= 1e-10 * abs(logdet)
+            systems.append((Rs, Os, b, float(m), float(ld)))
+        side = torch.cuda.Stream()
+        src = torch.empty(512 << 20, dtype=torch.uint8, device="cuda").random_(0, 255)
+        dst = torch.empty_like(src)
+        outs = []
+        for it in range(60):
+            if it % 3 != 2:                       # bursts, not a uniform background
+                with torch.cuda.stream(side):
+                    dst.copy_(src)
+            k = (it * 7 + it // 5) % len(systems)
+            outs.append((k, cr.mahal_and_det(*systems[k][:3])))
+            if it == 30:
+                _hip.check(_hip.lib().cgps_reset_counters(_hip.stream_ptr()))
+        torch.cuda.synchronize()
+        for k, (m, ld) in outs:
+            assert (float(m), float(ld)) == systems[k][3:], (k, float(m), float(ld), systems[k][3:])
+        # 1100 different workspaces (the library has 1024 slots): the results stay exact
+        Rs, Os, b, m0, ld0 = systems[0]
+        lib = _hip.lib()
+        ws, nb = _hip.workspace(Rs.shape[0], d, Rs.dtype, _hip.OP_MAHAL_LOGDET, Rs.device)
+        pool = torch.empty(nb + 256 * 1100, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(2, dtype=torch.float64, device="cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for i in range(1100):
+            wsp = ctypes.c_void_p(pool.data_ptr() + 256 * i)
+            _hip.check(lib.cgps_mahal_logdet(_hip.ptr(Rs), _hip.ptr(Os), _hip.ptr(b), Rs.shape[0], d, _hip.dtype_code(Rs.dtype),
+                                             wsp, nb, _hip.ptr(out), _hip.ptr(info), _hip.stream_ptr()))
+            if i % 100 == 99 or i >= 1090:
+                assert tuple(out.tolist()) == (m0, ld0), i
+    finally:
+        cr.CHECK_POSITIVE_DEFINITE = True
 
 
 @pytest.mark.parametrize("d,dtype", [(1, torch.float64), (2, torch.float64), (3, torch.float32), (4, torch.float64),
