@@ -179,6 +179,11 @@ class HipSolveOps:
         from . import cyclic_reduction as cr
         return cr.solve(dec, y)
 
+    @staticmethod
+    def inverse_blocks(dec):
+        from . import cyclic_reduction as cr
+        return cr.inverse_blocks(dec)
+
 
 class ShardedSolve:
     """x = J^-1 y for ONE block-tridiagonal system whose rows are split over the ranks (the posterior
@@ -236,6 +241,102 @@ class ShardedSolve:
                 self._interior = self.solve_ops.factor(self.Rs[:-1].contiguous(), self.Os[:n - 2].contiguous())
             x[:-1] = self.solve_ops.solve(self._interior, rhs)
         return x
+
+
+def boundary_recursions(recv, world, rec_bytes, msg_bytes, d, dtype, rank):
+    """What the rest of the system does to rank's rows, from the gathered records: eliminating every row LEFT of the
+    previous shard's last row a leaves that row the diagonal block P_a and right-hand side p_a; eliminating every row
+    RIGHT of this shard's last row s adds (dR_s, dy_s) to that row.  With w the shards in order, (Rs, Cs, dRa, ys, dya)_w
+    their records (RecordLayout in csrc/cgps_tile.h):
+        P_0 = Rs_0, p_0 = ys_0;  P_w = Rs_w - Cs_w (P_{w-1} + dRa_w)^-1 Cs_w^T,  p_w likewise          (left to right)
+        dR_{P-1} = 0;  dR_w = dRa_{w+1} - Cs_{w+1}^T (Rs_{w+1} + dR_{w+1})^-1 Cs_{w+1},  dy_w likewise  (right to left)
+    Returns (P_a, p_a) of a = rank - 1 (None, None on rank 0) and (dR_s, dy_s) of s = rank.  world small d x d steps."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    n_rec = rec_bytes // esz
+    msgs = recv.view(world, msg_bytes)[:, :rec_bytes].contiguous().view(dtype).view(world, n_rec).to(torch.float64)
+    dd = d * d
+    Rs = msgs[:, 0:dd].reshape(world, d, d)
+    Rs = 0.5 * (Rs + Rs.transpose(-1, -2))
+    Cs = msgs[:, dd:2 * dd].reshape(world, d, d)
+    dRa = msgs[:, 2 * dd:3 * dd].reshape(world, d, d)
+    dRa = 0.5 * (dRa + dRa.transpose(-1, -2))
+    ys = msgs[:, 3 * dd:3 * dd + d]
+    dya = msgs[:, 3 * dd + d:3 * dd + 2 * d]
+    Pa = pa = None
+    if rank > 0:
+        Pw, pw = Rs[0], ys[0]
+        for w in range(1, rank):
+            Z = torch.linalg.solve(Pw + dRa[w], torch.cat([Cs[w].T, (pw + dya[w])[:, None]], dim=1))
+            Pw, pw = Rs[w] - Cs[w] @ Z[:, :d], ys[w] - Cs[w] @ Z[:, d]
+        Pa, pa = Pw, pw
+    dR = torch.zeros(d, d, dtype=torch.float64, device=recv.device)
+    dy = torch.zeros(d, dtype=torch.float64, device=recv.device)
+    for w in range(world - 2, rank - 1, -1):
+        Z = torch.linalg.solve(Rs[w + 1] + dR, torch.cat([Cs[w + 1], (ys[w + 1] + dy)[:, None]], dim=1))
+        dR, dy = dRa[w + 1] - Cs[w + 1].T @ Z[:, :d], dya[w + 1] - Cs[w + 1].T @ Z[:, d]
+    cast = lambda t: None if t is None else t.to(dtype)   # noqa: E731
+    return cast(Pa), cast(pa), cast(dR), cast(dy)
+
+
+class ShardedPosterior:
+    """Posterior mean AND covariance blocks of ONE block-tridiagonal system whose rows are split over the ranks:
+    x = J^-1 y and the diagonal / lower off-diagonal blocks of J^-1 for this rank's rows -- what
+    compute_insample_posterior (reference models.py:282-298: decompose, solve, inverse_blocks) returns, for a system
+    too large for one GPU.  The reference has nothing like it.
+
+    The blocks of J^-1 inside a run of consecutive rows equal the inverse of that run's own sub-matrix once the rows
+    outside have been eliminated into its two end blocks (block-tridiagonal structure: marginalising the outside
+    touches nothing else).  So, with the same records and the same ONE all-gather as ShardedMahalLogdet / ShardedSolve:
+      1. every rank reduces its shard with the right-hand side to one record (cgps_shard_reduce);
+      2. all-gather; boundary_recursions() gives this rank what the shards to its left leave on the previous shard's
+         last row a (P_a, p_a) and what the shards to its right add to its own last row s (dR_s, dy_s);
+      3. the rank's LOCAL system -- row a (its block replaced by P_a), the shard's rows, the last one plus dR_s -- goes
+         through decompose + solve + inverse_blocks (the fused three-levels-per-launch kernels): mean and blocks of
+         its rows, and the block Sigma[first row, a] that belongs to the coupling across the shard boundary.
+    run(y) returns (mean [n_loc,d], Sig_diag [n_loc,d,d], Sig_off [n_loc-1 (+1 on ranks > 0),d,d]); on ranks > 0
+    Sig_off[0] is Sigma[first local row, last row of the previous rank], so the ranks' Sig_off pieces concatenate to the
+    global lower off-diagonal.  `ops`, `solve_ops`, `gather`: as in ShardedSolve."""
+
+    def __init__(self, Rs, Os, O_left, n_total, rank, world, group=None, ops=None, solve_ops=None, gather=None):
+        self.Rs, self.Os, self.O_left = Rs, Os, O_left
+        self.n_total, self.rank, self.world = n_total, rank, world
+        self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
+        self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
+        self.solve_ops = solve_ops if solve_ops is not None else HipSolveOps
+        self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
+        dev = Rs.device
+        self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.recv = torch.zeros(world * self.msg_bytes, dtype=torch.uint8, device=dev)
+        self.gather = gather if gather is not None else _default_gather(group)
+
+    def reduce_to_send(self, y):
+        self.ops.shard_reduce(self.Rs, self.Os, y, self.O_left, self.send, self.rec_bytes)
+        return self.send
+
+    def run(self, y):
+        d, r = self.d, self.rank
+        y = y.contiguous()
+        self.reduce_to_send(y)
+        if self.world > 1:
+            self.gather(self.send, self.recv)
+            src = self.recv
+        else:
+            src = self.send
+        Pa, pa, dR, dy = boundary_recursions(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype, r)
+        if r > 0:
+            R_loc = torch.cat([Pa[None], self.Rs])
+            O_loc = torch.cat([self.O_left[None], self.Os])
+            y_loc = torch.cat([pa[None], y])
+        else:
+            R_loc, O_loc, y_loc = self.Rs.clone(), self.Os, y.clone()
+        R_loc[-1] += dR
+        y_loc[-1] += dy
+        dec = self.solve_ops.factor(R_loc.contiguous(), O_loc.contiguous())
+        mean = self.solve_ops.solve(dec, y_loc.contiguous())
+        Sd, So = self.solve_ops.inverse_blocks(dec)
+        if r > 0:
+            return mean[1:], Sd[1:], So
+        return mean, Sd, So
 
 
 def make_sharded_system(n_total, d, dtype, device, rank, world, group=None, seed=1234):

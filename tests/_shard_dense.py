@@ -117,3 +117,7 @@ class OracleSolveOps:
     @staticmethod
     def solve(dec, y):
         return O.solve(dec, y)
+
+    @staticmethod
+    def inverse_blocks(dec):
+        return O.inverse_blocks(dec)

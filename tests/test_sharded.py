@@ -274,3 +274,106 @@ def test_sharded_solve_plan_world1_on_gpu():
     plan = sharded.ShardedSolve(Rs, Os, O_left, n, 0, 1)
     assert float((plan.run(b) - x_true).abs().max()) < 1e-9
     assert float((plan.run(3 * b) - 3 * x_true).abs().max()) < 1e-9
+
+
+# ---- sharded posterior: mean + covariance blocks of a system split over ranks (ShardedPosterior) -----------------
+def _run_posterior_ranks(Rs, Os, b, parts, **kw):
+    """The ranks played one after the other through an injected gather; returns per-rank (mean, Sig_diag, Sig_off)."""
+    n = Rs.shape[0]
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    sends, plans = [], []
+    for r, (lo, hi) in enumerate(bounds):
+        pl = sharded.ShardedPosterior(Rs[lo:hi].contiguous(), Os[lo:hi - 1].contiguous(), Os[lo - 1].contiguous() if lo else None,
+                                      n, r, parts, gather=lambda send, recv: recv.copy_(torch.cat(sends)), **kw)
+        sends.append(pl.reduce_to_send(b[lo:hi].contiguous()).clone())
+        plans.append(pl)
+    return bounds, [plans[r].run(b[lo:hi].contiguous()) for r, (lo, hi) in enumerate(bounds)]
+
+
+@pytest.mark.parametrize("n,d,parts", [(40, 3, 4), (9, 2, 5), (5, 2, 5), (257, 4, 3), (33, 1, 2)])
+def test_sharded_posterior_algebra_against_oracle(n, d, parts):
+    """Mean and the diagonal / off-diagonal blocks of J^-1 of every rank's rows (the coupling block across each shard
+    boundary included; shards of one row included) equal the oracle's solve / inverse_blocks of the whole system."""
+    Rs, Os, b, _, _ = _util.conditioned_system(n, d, seed=7 + n)
+    bounds, res = _run_posterior_ranks(Rs, Os, b, parts, ops=SD.DenseShardOps(d), solve_ops=SD.OracleSolveOps)
+    dec = O.decompose(Rs, Os)
+    Sd0, So0 = O.inverse_blocks(dec)
+    x0 = O.solve(dec, b)
+    for (lo, hi), (mean, Sd, So) in zip(bounds, res):
+        np.testing.assert_allclose(mean.numpy(), x0[lo:hi].numpy(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Sd.numpy(), Sd0[lo:hi].numpy(), rtol=0, atol=1e-12)
+        ref = So0[lo - 1:hi - 1] if lo else So0[:hi - 1]
+        assert So.shape == ref.shape
+        np.testing.assert_allclose(So.numpy(), ref.numpy(), rtol=0, atol=1e-12)
+
+
+def _gloo_posterior_worker(rank, world, port, n_total, d, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Rs, Os, b, O_left, _, _ = sharded.make_sharded_system(n_total, d, torch.float64, torch.device("cpu"), rank, world)
+        x_true = sharded.make_sharded_system.last_x_true
+        plan = sharded.ShardedPosterior(Rs, Os, O_left, n_total, rank, world, ops=SD.DenseShardOps(d), solve_ops=SD.OracleSolveOps)
+        mean, Sd, So = plan.run(b)
+        full = [None] * world
+        dist.all_gather_object(full, (Rs, Os, O_left, Sd, So, float((mean - x_true).abs().max())))
+        if rank == 0:
+            R = torch.cat([f[0] for f in full])
+            Oall = torch.cat([t for r, f in enumerate(full) for t in (([f[2][None]] if r > 0 else []) + [f[1]])])
+            Sd0, So0 = O.inverse_blocks(O.decompose(R, Oall))
+            q.put(dict(err_mean=max(f[5] for f in full), err_d=float((torch.cat([f[3] for f in full]) - Sd0).abs().max()),
+                       err_o=float((torch.cat([f[4] for f in full]) - So0).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,d", [(2, 65, 3), (3, 10, 2)])
+def test_sharded_posterior_under_gloo(world, n_total, d):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_gloo_posterior_worker, args=(world, _free_port(), n_total, d, q), nprocs=world, join=True)
+    res = q.get()
+    assert res["err_mean"] < 1e-9 and res["err_d"] < 1e-12 and res["err_o"] < 1e-12, res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,parts,dtype", [(5000, 4, 4, torch.float64), (70001, 3, 5, torch.float64), (9, 4, 5, torch.float64),
+                                             (2 ** 20, 4, 8, torch.float64), (40000, 8, 3, torch.float32),
+                                             (2 ** 18 + 5, 5, 8, torch.float64)])
+def test_sharded_posterior_on_one_gpu(n, d, parts, dtype):
+    """ShardedPosterior with the HIP kernels, eight (or fewer) ranks played in sequence on one GPU: mean against the
+    planted solution, covariance blocks against inverse_blocks of the whole system on the same GPU."""
+    import cyclic_gps.cyclic_reduction as cr
+    Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=3 + n)
+    bounds, res = _run_posterior_ranks(Rs, Os, b, parts)
+    Sd0, So0 = cr.inverse_blocks(cr.decompose(Rs, Os))
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    for (lo, hi), (mean, Sd, So) in zip(bounds, res):
+        assert float((mean - x_true[lo:hi]).abs().max()) <= tol
+        assert float((Sd - Sd0[lo:hi]).abs().max()) <= tol
+        ref = So0[lo - 1:hi - 1] if lo else So0[:hi - 1]
+        assert So.shape == ref.shape and (ref.numel() == 0 or float((So - ref).abs().max()) <= tol)
+
+
+@pytest.mark.gpu
+def test_sharded_posterior_config4_shape():
+    """N = 2^24 rows (BASELINE config 4) as eight shards: rank 5's blocks satisfy (J Sigma)_ii = I on its rows -- the
+    block-diagonal of J Sigma needs exactly the blocks the rank returns (its coupling across the shard boundary included)."""
+    n, d, parts, r = 2 ** 24, 4, 8, 5
+    Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, device="cuda")
+    bounds = [sharded.shard_bounds(n, parts, k) for k in range(parts)]
+    sends = []
+    for k, (lo, hi) in enumerate(bounds):
+        pl = sharded.ShardedPosterior(Rs[lo:hi], Os[lo:hi - 1], Os[lo - 1].contiguous() if lo else None, n, k, parts,
+                                      gather=lambda send, recv: recv.copy_(torch.cat(sends)))
+        sends.append(pl.reduce_to_send(b[lo:hi]).clone())
+        if k == r:
+            plan = pl
+    lo, hi = bounds[r]
+    mean, Sd, So = plan.run(b[lo:hi])
+    assert float((mean - x_true[lo:hi]).abs().max()) < 1e-9
+    # rows lo .. hi-2 (the last row's right coupling belongs to rank r + 1): R_i S_ii + O_{i-1} S_{i,i-1}^T + O_i^T S_{i+1,i}
+    Rl, Ol = Rs[lo:hi - 1], Os[lo - 1:hi - 2]
+    JS = Rl @ Sd[:-1] + Ol @ So[:-1].transpose(-1, -2) + Os[lo:hi - 1].transpose(-1, -2) @ So[1:]
+    eye = torch.eye(d, dtype=JS.dtype, device=JS.device)
+    assert float((JS - eye).abs().max()) < 1e-10
