@@ -508,6 +508,15 @@ __device__ __forceinline__ void collect_left_updates(LdsTile<T, D>& t, int level
   }
 }
 
+// Fail codes: 1 + a row near the block that was not positive definite.  A failure poisons everything downstream (NaN),
+// so the in-LDS levels and the record stages after it fail as well, at rows that have nothing to do with the cause:
+// their codes carry FAIL_LATE, the smallest code wins, so a failure of the streaming stage (the lane's own chunk) is
+// what `info` reports whenever there is one; the flag is stripped when `info` is written.
+constexpr int FAIL_LATE = 0x40000000;
+__device__ __forceinline__ int fail_code(bool early, bool any, int64_t row) {
+  const int r = (int)(row < (int64_t)(FAIL_LATE - 2) ? row : (int64_t)(FAIL_LATE - 2)) + 1;
+  return early ? r : (any ? (r | FAIL_LATE) : 0);
+}
 template <int NT>
 __device__ __forceinline__ void write_partial(double mah, double logp, int failrow_plus1, double* __restrict__ partial,
                                               double* red, int* sfail) {
@@ -703,6 +712,7 @@ struct FoldArgs {
   int* info;
   void* shard_record;              // ... or one shard of a larger system (non-null): its single record
   double* shard_partial;           //     and its {sum of squares, sum of log pivots, fail, 0}
+  int rows_per_lane;               // chunk_reduce_kernel<.., C = 0, ..>: rows per lane given at run time (a multiple of 4)
 };
 template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL = false>
 __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
@@ -789,7 +799,11 @@ __device__ __forceinline__ void fold_record_stages(char* smem, int* last_flag, T
     }
 }
 
-template <typename T, int D, int C, int NT, int NW = NT, bool FOLD = false>
+// C = 0: the rows per lane come with the launch (fold.rows_per_lane, a multiple of 4).  A system of more rows than
+// one round of the chip at the compiled C is still ONE round then -- every lane simply walks a longer chunk -- so
+// the serial tail (in-LDS levels, record stages) is paid once per launch instead of once per round, and nothing
+// but the last round's tail of a multi-round grid ever had the memory system to itself anyway.
+template <typename T, int D, int CT, int NT, int NW = NT, bool FOLD = false>
 __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
                                                           const T* __restrict__ Oleft,
@@ -803,8 +817,15 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   const int tid = threadIdx.x;
   CGPS_KSTAMP(0);
   if (tid == 0) *sm.sfail = 0x7fffffff;
+  const int C = CT > 0 ? CT : fold.rows_per_lane;
   const int64_t lane0 = (int64_t)blockIdx.x * NT;
-  const int64_t r0 = tid < NT ? (lane0 + tid) * C : N;          // threads past the lanes hold no rows
+  const int64_t gl = lane0 + tid;
+  int64_t r0 = gl * C, rE = gl * C + C;                         // this lane's chunk [r0, rE)
+  if (tid >= NT) r0 = N;                                        // threads past the lanes hold no rows
+  const bool whole_chunk = rE <= N;                             // the lane's chunk is complete
+  const bool whole_chunk_and_next = rE <= N - 1;                // ... and the row after it exists
+  if (rE > N) rE = N;
+  const int L = r0 < N ? (int)(rE - r0) : 0;                    // rows of this lane
   PivotLog pl;
   double mah = 0.0;
   bool fail = false;
@@ -821,9 +842,9 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   // is fetched again (PMC: 1.15 x the algorithmic bytes leave L2 that way).  Such lanes copy the
   // whole line into their 128 bytes of the (still idle) LDS tile when they reach it.
   constexpr int YR = 4;
-  constexpr bool YSTAGE = std::is_same<T, double>::value && D == 4 && C >= YR && C % YR == 0;
+  constexpr bool YSTAGE = std::is_same<T, double>::value && D == 4 && (CT == 0 || (CT >= YR && CT % YR == 0));
   T* ylds = reinterpret_cast<T*>(smem) + (size_t)tid * (YR * D);
-  const bool yfull = YSTAGE && (r0 + C <= N);              // the lane's chunk is complete: whole lines exist
+  const bool yfull = YSTAGE && whole_chunk && r0 < N;      // the lane's chunk is complete: whole lines exist
   auto stage_y_line = [&](int64_t row) {                   // rows row .. row+YR-1 -> this lane's LDS line
     if constexpr (YSTAGE) {
       using V = typename Vec16<T>::type;
@@ -834,8 +855,8 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
     }
   };
   constexpr int RG = stage1_row_group<T, D>();
-  constexpr bool GROUPED = RG > 1 && C % RG == 0 && !YSTAGE;
-  const bool grouped = GROUPED && (r0 + C <= N - 1);      // every row of the chunk, and O[r0 + C - 1], exist
+  constexpr bool GROUPED = RG > 1 && CT % RG == 0 && !YSTAGE;
+  const bool grouped = GROUPED && whole_chunk_and_next && r0 < N;   // every row of the chunk, and O[last row], exist
   if (r0 < N) {
     if (!grouped) {
       load_block<T, D>(Rg + r0 * DD, Rc);
@@ -861,7 +882,7 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
     if (grouped) {
       T Oc[D][D];                              // O[a - 1], carried
 #pragma unroll 1
-      for (int p = 0; p < C / RG; ++p) {
+      for (int p = 0; p < L / RG; ++p) {
         const int64_t a = r0 + (int64_t)RG * p;
         T Rq[RG][D][D], Oq[RG][D][D], yq[RG][D];
         load_rows<T, D, RG>(Rg + a * DD, Rq);
@@ -893,9 +914,8 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   }
   if (!grouped) {
 #pragma unroll 1
-  for (int j = 0; j < C - 1; ++j) {
+  for (int j = 0; j < L - 1; ++j) {
     const int64_t rn = r0 + j + 1;
-    if (rn >= N) break;
     T Rn[D][D], On[D][D], yn[D];
     load_block<T, D>(Rg + rn * DD, Rn);
     load_block<T, D>(Og + (rn - 1) * DD, On);
@@ -912,13 +932,14 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   // is still reading its y line then)
 
   CGPS_KSTAMP(1);
+  const bool fail_stream = fail;                 // (what fails later may be a consequence of this)
   int64_t nreal64 = (N + C - 1) / C - lane0;     // lanes of this tile that hold real rows
   const int n_real = nreal64 > NT ? NT : (int)nreal64;
   reduce_tile_and_emit<T, D, NW>(sm.t, Rc, yc, Cc, dRa, dya, n_real, sm.xch, rec + (size_t)blockIdx.x * RecordLayout<T, D>::STRIDE,
                                  pl, mah, fail);
   CGPS_KSTAMP(2);
   int64_t frow = r0 < N ? r0 : N - 1;
-  write_partial<NW>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
+  write_partial<NW>(mah, pl.value(), fail_code(fail_stream, fail, frow), partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
   CGPS_KSTAMP(3);
   if constexpr (FOLD)
     fold_record_stages<T, D, NW, (NW == 2 * NT)>(smem, sm.sfail + 1, rec, partial, fold, (int64_t)C * NT, N);
@@ -1122,7 +1143,7 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
   frow = (frow < N ? frow : N) - 1;
   if constexpr (!FINAL) {
     double logp = pl.value();
-    int fcode = fail ? (int)(frow + 1) : 0;
+    int fcode = fail_code(false, fail, frow);
     if (partial_in != nullptr) {           // last launch of a shard: fold in the partial results of the earlier ones
       for (int64_t i = tid; i < n_partial; i += NT) {
         const double* p = partial_in + pstride * i;
@@ -1145,7 +1166,7 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
       for (int i = 0; i < D; ++i) mah += (double)x[i] * (double)x[i];
     }
     CGPS_FSTAMP(4);
-    if (fail) atomicMin(sm.sfail, (int)(frow + 1));
+    if (fail) atomicMin(sm.sfail, fail_code(false, true, frow));
     double logp = pl.value() + pre_logp;
     mah += pre_mah;
     if (pre_fail != 0x7fffffff) atomicMin(sm.sfail, pre_fail);
@@ -1158,7 +1179,7 @@ __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_ind
       const double poison = __builtin_nan("");
       out2[0] = ok ? mah : poison;
       out2[1] = ok ? logp : poison;
-      *info = ok ? 0 : f;
+      *info = ok ? 0 : (f & ~FAIL_LATE);
     }
     CGPS_FSTAMP(5);
   }
@@ -1244,7 +1265,11 @@ void tile_set_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
   } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, Cfg::NT1, true>),
@@ -1254,6 +1279,9 @@ void tile_set_attributes() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1));
     }
@@ -1326,6 +1354,44 @@ inline bool fold_final_enabled() {          // CGPS_NO_FOLD=1: two launches as b
   return on;
 }
 
+// Systems of more rows than one round of the chip at the compiled rows-per-lane: rows per lane chosen at launch so
+// that the grid is still ONE round (long_chunk_tiles() workgroups at most; CGPS_S1_TILES=<n> for A/B timing,
+// CGPS_S1_LONG=0: rounds of the compiled-C kernel as before).  Returns 0 when the compiled C is to be used.
+inline int long_chunk_target_tiles() {
+  static const int v = [] {
+    const char* e = getenv("CGPS_S1_LONG");
+    if (e && e[0] == '0') return 0;
+    const char* t = getenv("CGPS_S1_TILES");
+    const int n = t ? atoi(t) : 0;
+    return n > 0 ? n : (int)STAGE1_SMALL_TILES;
+  }();
+  return v;
+}
+inline bool long_chunk_narrow() {          // CGPS_S1_NARROW=1: the long chunks on the two-workgroups-per-CU kernel (A/B)
+  static const bool on = [] { const char* e = getenv("CGPS_S1_NARROW"); return e && e[0] == '1'; }();
+  return on;
+}
+// block_bytes: bytes of one d x d block.  The lanes of a wave read addresses C * block_bytes apart, all lanes of the
+// chip at the same offset inside their chunks; measured (profiles/r03_long_chunk_sweep.txt, d = 4 fp64): strides of
+// 4 KB and 8 KB stream at 4.3-5.9 TB/s depending on the box (the physical placement of the operands: L1->L2 read
+// latency 1 480 cycles against 1 200 and twice the DRAM credit stalls in the slow case), 2 KB and >= 16 KB at
+// 6.1-6.5 TB/s on every box seen.  Long chunks are therefore taken only outside (2 KB, 16 KB); in between the
+// compiled C runs in rounds as before (CGPS_S1_C=<c> forces a value for A/B timing).
+inline int long_chunk_rows_per_lane(int64_t N, int lanes, int c_full, int block_bytes) {
+  const int tiles = long_chunk_target_tiles();
+  if (tiles <= 0) return 0;
+  static const int forced = [] { const char* e = getenv("CGPS_S1_C"); return e ? atoi(e) : 0; }();   // A/B timing
+  if (forced > 0 && forced % 4 == 0 && (N + (int64_t)forced * lanes - 1) / ((int64_t)forced * lanes) <= 1024 &&
+      N > (int64_t)forced * lanes)
+    return forced;
+  const int64_t per_round = (int64_t)tiles * lanes;
+  int64_t c = (N + per_round - 1) / per_round;
+  c = (c + 3) & ~(int64_t)3;
+  if (c <= c_full || c > (1 << 20)) return 0;
+  if (c * block_bytes > 2048 && c * block_bytes < 16384) return 0;
+  return (int)c;
+}
+
 // The fused pipeline.  Whole system: shard_record == nullptr, results in out2 / info.
 // One shard of a sharded system: shard_record / shard_partial receive the shard's single record
 // and its {mahal, logdet, fail, 0} partial; Oleft = J[first row of the shard, last row of the
@@ -1339,7 +1405,8 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   using RL = RecordLayout<T, D>;
   if (ws_bytes < tile_ws_bytes(N, D, sizeof(T))) return -1;
   if (Cfg::ROWS1 != tile_rows1(D, sizeof(T))) return -1;   // the two definitions of ROWS1 must agree
-  const int csel = (Cfg::LPR > 1 || Cfg::ALWAYS_WIDE) ? Cfg::C : stage1_rows_per_lane(N, Cfg::C, Cfg::NT1);
+  const int clong = (Cfg::LPR > 1 || !fold_final_enabled()) ? 0 : long_chunk_rows_per_lane(N, Cfg::NG1, Cfg::C, (int)(D * D * sizeof(T)));
+  const int csel = clong > 0 ? clong : ((Cfg::LPR > 1 || Cfg::ALWAYS_WIDE) ? Cfg::C : stage1_rows_per_lane(N, Cfg::C, Cfg::NT1));
   const int64_t rows_per_tile = (int64_t)csel * Cfg::NG1;
   const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
   const int64_t tiles_cap = tile_cap(N, D, sizeof(T));
@@ -1365,6 +1432,13 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
   else if constexpr (Cfg::ALWAYS_WIDE) {
     const int slot = (tiles > 1 && tiles <= (int64_t)FOLD_GROUP * FOLD_MAX_GROUPS && fold_final_enabled()) ? fold_slot_for(ws) : -1;
     const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+    if (slot >= 0 && clong > 0) {
+      const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial, clong};
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
+                         dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      if (ev_stop) (void)hipEventRecord(ev_stop, st);
+      return 0;
+    }
     if (slot >= 0) {
       const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial};
       hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
@@ -1374,6 +1448,24 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
     }
     hipLaunchKernelGGL((chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1, 2 * Cfg::NT1>), dim3((unsigned)tiles),
                        dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, FoldArgs{});
+  } else if (clong > 0) {
+    // more rows than one round of the chip: one round of longer chunks (see long_chunk_target_tiles)
+    const int slot = fold_slot_for(ws);
+    const FoldArgs fa{slot, recB, out2, info, shard_record, shard_partial, clong};
+    bool wide = false;
+    if constexpr (stage1_min_waves<T, D>() == 2) {
+      if (!long_chunk_narrow()) {
+        wide = true;
+        const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+        hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true>), dim3((unsigned)tiles),
+                           dim3(2 * Cfg::NT1), ldsw, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+      }
+    }
+    if (!wide)
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 0, Cfg::NT1, Cfg::NT1, true>), dim3((unsigned)tiles), dim3(Cfg::NT1),
+                         lds1, st, Rs, Os, x, N, Oleft, recA, partial, fa);
+    if (ev_stop) (void)hipEventRecord(ev_stop, st);
+    return 0;
   } else if (csel != Cfg::C) {
     // small systems (fewer rows per lane, at most one workgroup per CU): the same one-launch form --
     // no faster on the GPU's clock than two launches (measured 2^14 .. 2^19 rows), but one node in a

@@ -260,10 +260,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 4 ? 2 : 1)) void chunk_reduce_ml_
       sm.xch[DD + row_lo + t] = dya[t];
     }
   }
+  const bool fail_stream = fail;                 // (what fails later may be a consequence of this: fail_code)
   // barrier, cyclic reduction of the tile's kept rows, the record (D * D lanes, write-through stores)
   reduce_staged_tile_and_emit<T, D, NT>(sm.t, n_real, sm.xch, rec + (size_t)blockIdx.x * RL::STRIDE, pl, mah, fail);
   int64_t frow = r0 < N ? r0 : N - 1;
-  write_partial<NT>(mah, pl.value(), fail ? (int)(frow + 1) : 0, partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
+  write_partial<NT>(mah, pl.value(), fail_code(fail_stream, fail, frow), partial + PARTIAL_STRIDE * (size_t)blockIdx.x, sm.red, sm.sfail);
   if constexpr (FOLD)
     fold_record_stages<T, D, NT, false>(smem, sm.sfail + 1, rec, partial, fold, (int64_t)C * NG, N);
 }

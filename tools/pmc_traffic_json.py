@@ -34,7 +34,19 @@ f_avg, w_avg = sum(f) / len(f), sum(w) / len(w)
 N, d, s = 1 << 20, 4, 8
 alg = ((2 * N - 1) * d * d + N * d) * s + 2 * s
 hbm = 2 * f_avg * 1024 + w_avg * 1024
-sha = lambda n: hashlib.sha256(open(os.path.join(CSRC, n), "rb").read()).hexdigest()[:16]   # noqa: E731
+
+
+def kernel_source_sha16():
+    """The digest bench.py computes (bench.kernel_source_sha16): every header under csrc/, cgps_mahal.hip, include/cgps.h."""
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["cgps_mahal.hip"]
+    h = hashlib.sha256()
+    for f in names:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cgps.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 doc = {
     "round": rnd,
     "command": "bash tools/pmc_traffic.sh OUT  (= rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 "
@@ -51,7 +63,7 @@ doc = {
     "hbm_bytes_per_launch": hbm,
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": hbm / alg,
-    "kernel_source_sha16": {n: sha(n) for n in ("cgps_tile.h", "cgps_tile_mfma.h", "cgps_math.h")},
+    "kernel_source_sha16": kernel_source_sha16(),
 }
 dst = os.path.join(ROOT, "profiles", "r%02d_pmc_traffic.json" % rnd)
 json.dump(doc, open(dst, "w"), indent=1)
