@@ -34,9 +34,15 @@ struct DecompLevelsL {
   int nlev;
 };
 
-template <typename T, int D>
+// Blocks whose 256-row tile does not fit the LDS (fp64 d = 6, 7, 8) take tiles of 2^6 rows, six levels per launch,
+// for EVERY pass of their factorisation (cgps_decompose.hip: run_decompose_lds_only) -- 2^20 rows in four launches
+// instead of one per level; two to four such tiles share a CU.
+template <typename T, int D> constexpr int decomp_lds_lp() {
+  return (((size_t)DECL_TS * 2 * D * D + D * D) * sizeof(T) + 4096 <= 160 * 1024) ? DECL_LP : 6;
+}
+template <typename T, int D, int LP = DECL_LP>
 constexpr size_t decomp_lds_tile_bytes() {
-  return (((size_t)DECL_TS * 2 * D * D + D * D) * sizeof(T) + 15 & ~(size_t)15) + 256;
+  return (((size_t)(1 << LP) * 2 * D * D + D * D) * sizeof(T) + 15 & ~(size_t)15) + 256;
 }
 
 // Reduction of the n0-row tile with factor emission.  keep_last: the tile's last row is a
@@ -283,27 +289,28 @@ __device__ __forceinline__ int tile_cr_factor_quad(LdsTile<T, D>& t, int n0, boo
 // One pass of the factorisation.  FROM_RECORDS = false: rows are the caller's Rs / Os (level 0).
 // FROM_RECORDS = true: rows are the previous pass's records (RecordLayout without the vector
 // parts): R = Rs[w] + dRa[w+1], coupling to the previous row Cs[w].
-template <typename T, int D, bool FROM_RECORDS>
+template <typename T, int D, bool FROM_RECORDS, int LP = DECL_LP>
 __global__ __launch_bounds__(DECL_NT) void decomp_lds_kernel(const T* __restrict__ Rin, const T* __restrict__ Oin,
                                                              int64_t n, int64_t n_rec, int spt_in, DecompLevelsL lv,
                                                              int lvl_first,
                                                              T* __restrict__ Dp, T* __restrict__ Fp,
                                                              T* __restrict__ Gp, T* __restrict__ rec_out,
                                                              int* __restrict__ info) {
-  constexpr int DD = D * D;
+  constexpr int DD = D * D, TS = 1 << LP;
+  static_assert(TS <= DECL_NT, "one thread loads one row of the tile");
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LdsTile<T, D> t;
   t.R = reinterpret_cast<T*>(smem);
-  t.Oc = t.R + (size_t)DECL_TS * DD;
+  t.Oc = t.R + (size_t)TS * DD;
   t.y = nullptr;
   const int tid = threadIdx.x;
-  const int64_t row0 = (int64_t)blockIdx.x * DECL_TS;
-  const int n0 = (int)((n - row0) < DECL_TS ? (n - row0) : DECL_TS);
+  const int64_t row0 = (int64_t)blockIdx.x * TS;
+  const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
   // A full tile running exactly LP levels ends with its last row still alive (odd at every one of
   // those levels): that row is handed on as a record.  A ragged tile (only the last one can be)
   // and the single tile of the top pass are reduced to nothing, by the reference's size rule.
-  const bool keep_last = (n0 == DECL_TS) && (lv.nlev == DECL_LP);
+  const bool keep_last = (n0 == TS) && (lv.nlev == LP);
   // rows of the tile -> LDS
   if (tid < n0) {
     const int64_t w = row0 + tid;

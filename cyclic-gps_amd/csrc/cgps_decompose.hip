@@ -104,6 +104,83 @@ int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp,
   (void)RL::STRIDE;
   return check_launch("decompose (tiled)");
 }
+
+// ---- blocks whose 256-row tile does not fit the LDS (fp64 d = 6, 7, 8): passes of cgps_decomp_lds.h with 64-row
+// tiles, six levels per launch (2^20 rows: 2^20 -> 2^14 -> 2^8 -> 4 -> done; level by level: 21 launches, every
+// level's rows written and read back).  Measured (prof_case --op decompose, 2^20 rows, level by level -> this):
+// d = 6 1 084 -> 836 us.  For d = 7, 8 the tile passes are bound by their two workgroups per CU (65 KB of LDS per
+// 8 x 8 tile): 1 588 -> 1 931 us and 1 836 -> 2 278 us at 2^20 rows, but 263 -> 170 / 330 -> 164 us at 2^14 and
+// 334 -> 269 / 403 -> 276 us at 2^16 (a tie at 2^18) -- so those sizes run their levels of more than 2^17 rows one
+// launch per level (level_kernel, full occupancy) and hand over to the tile passes below that. --------------------
+template <typename T, int D>
+int run_decompose_lds_only(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
+                           hipStream_t st) {
+  constexpr int LP = cgps::decomp_lds_lp<T, D>(), TS = 1 << LP;
+  LevelWs w = level_ws(N, D, sizeof(T), true, false);
+  if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
+  Layout L;
+  make_layout(N, L);
+  const size_t lds = cgps::decomp_lds_tile_bytes<T, D, LP>();
+  struct Done { int ok; };
+  static PerDevice<Done> attr;
+  (void)attr.get([&](int) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, false, LP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::decomp_lds_kernel<T, D, true, LP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return Done{1};
+  });
+  (void)hipMemsetAsync(info, 0, sizeof(int), st);
+  T* recs[2] = {reinterpret_cast<T*>(ws + w.a_off), reinterpret_cast<T*>(ws + w.b_off)};
+  const T* rin = nullptr;
+  int64_t n_rec = 0;
+  int lvl = 0, p = 0;
+  // the levels too large for the tile passes (d = 7, 8), one launch each; their output alternates between the two
+  // level buffers, which are also the record buffers of the tile passes: the first tile pass writes the other one
+  constexpr int64_t LDS_MAX_ROWS = (D >= 7) ? (int64_t)131072 : ((int64_t)1 << 62);
+  LevelBuf<T> bufs[2] = {carve<T>(ws + w.a_off, w.capA, D, true, false), carve<T>(ws + w.b_off, w.capB, D, true, false)};
+  double* partial = reinterpret_cast<double*>(ws + w.partial_off);
+  const T *Rl = Rs, *Ol = Os;
+  int64_t pb = 0;
+  int out_idx = 0;
+  while (lvl < L.nlevels - 1 && L.ms[lvl] > LDS_MAX_ROWS) {
+    const int64_t n = L.ms[lvl], nb = level_blocks(n);
+    LevelBuf<T>& nx = bufs[lvl & 1];
+    hipLaunchKernelGGL((cgps::level_kernel<T, D, true, false>), dim3((unsigned)nb), dim3(cgps::LEVEL_THREADS), 0, st, Rl, Ol,
+                       (const T*)nullptr, n, lvl, Dp + L.offD[lvl] * D * D, Fp + L.offF[lvl] * D * D, Gp + L.offG[lvl] * D * D,
+                       (T*)nullptr, nx.R, nx.O, nx.y, partial + 2 * pb, info);
+    pb += nb;
+    Rl = nx.R;
+    Ol = nx.O;
+    out_idx = (lvl & 1) ^ 1;
+    ++lvl;
+  }
+  while (lvl < L.nlevels) {
+    const int64_t rows = L.ms[lvl];
+    const int remaining = L.nlevels - lvl;
+    const int64_t g = (rows + TS - 1) / TS;
+    const int nl = (g == 1) ? remaining : LP;                              // <= LP + 1
+    cgps::DecompLevelsL dl;
+    dl.nlev = nl;
+    for (int j = 0; j < cgps::DECL_MAXLEV; ++j) {
+      const int l = lvl + j < L.nlevels ? lvl + j : L.nlevels - 1;
+      dl.offD[j] = L.offD[l]; dl.offF[j] = L.offF[l]; dl.offG[j] = L.offG[l];
+    }
+    T* rout = recs[out_idx];
+    out_idx ^= 1;
+    if (p == 0)
+      hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, false, LP>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds, st, Rl, Ol,
+                         rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
+    else
+      hipLaunchKernelGGL((cgps::decomp_lds_kernel<T, D, true, LP>), dim3((unsigned)g), dim3(cgps::DECL_NT), lds, st, rin,
+                         (const T*)nullptr, rows, n_rec, 1, dl, lvl, Dp, Fp, Gp, rout, info);
+    rin = rout;
+    n_rec = g;
+    lvl += nl;
+    ++p;
+  }
+  return check_launch("decompose (in-LDS passes)");
+}
 }  // namespace
 
 extern "C" {
@@ -117,10 +194,14 @@ int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, 
     constexpr int D = decltype(dc)::value;
     // tiled form for every block size whose 256-row tile fits the LDS (no register spills up to
     // 8x8 fp32 / 5x5 fp64); larger blocks go level by level
-    if constexpr (cgps::decomp_tile_supported<T, D>()) {
+    if constexpr (cgps::tile_fits_256<T, D>()) {
       if (!levelwise_solve_requested())
         return run_decompose_tile<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, ws_bytes,
                                         info, (hipStream_t)stream);
+    } else {
+      if (!levelwise_solve_requested())
+        return run_decompose_lds_only<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, ws_bytes,
+                                            info, (hipStream_t)stream);
     }
     return run_levelwise<T, D>((const T*)Rs, (const T*)Os, nullptr, N, (T*)Dp, (T*)Fp, (T*)Gp, nullptr, (char*)ws,
                                ws_bytes, nullptr, info, (hipStream_t)stream);

@@ -192,8 +192,10 @@ def test_not_positive_definite_raises():
     (2 ** 20, 7, torch.float32, 2e-5),
     (2 ** 20 + 3, 6, torch.float64, 1e-10),
     (2 ** 20, 8, torch.float64, 1e-10),
+    # fp64 d = 7: decompose = levels of more than 2^17 rows one launch each, then 64-row tile passes (cgps_decompose.hip)
+    (2 ** 18 + 2 ** 17 + 5, 7, torch.float64, 1e-10),
 ], ids=["c2_N2^20_d4_f64", "c3_N2^22_d8_f32", "ragged_d4_f64", "ragged_d5_f64", "c4_N2^24_d4_f64", "d1_f64", "d2_f64",
-        "d3_f64", "d2_f32", "d3_f32", "d6_f32", "d7_f32", "d6_f64", "d8_f64"])
+        "d3_f64", "d2_f32", "d3_f32", "d6_f32", "d7_f32", "d6_f64", "d8_f64", "d7_f64"])
 def test_full_size_closed_form(N, d, dtype, rtol):
     """Size-independent properties at the benchmark sizes: J = L L^T with L block
     bidiagonal, so log|J| and the planted solution x_true are known in closed form."""
