@@ -382,6 +382,34 @@ def extra_measurements(dev):
             res["posterior_mean_max_abs_err_vs_reference"] = float(
                 (mean.cpu() - torch.from_numpy(g["post_mean"])).abs().max())
         out["c5_leg_co2like"] = res
+        # the same reductions at 2^20 rows on a regular grid, rank 5: operands assembled in registers inside the first
+        # pass (cgps_leg_mahal_logdet: only ts and v are read from HBM) against cgps_peg_precision -> blocks in HBM ->
+        # cgps_mahal_logdet; PMC traffic of the fused launch: profiles/r03_pmc_traffic_leg_fused.txt
+        try:
+            nl = 1 << 20
+            G5 = m.G
+            A5 = (m.B.T @ m.LLT_inv @ m.B).contiguous()
+            tsl = 0.25 * torch.arange(nl, dtype=torch.float64, device=dev)
+            vl = torch.randn(nl, G5.shape[0], dtype=torch.float64, device=dev)
+            cr.CHECK_POSITIVE_DEFINITE = False
+            t_f = _time_cuda(lambda: leg.leg_mahal_and_det(tsl, G5, A5, vl), 10)
+            Rl, Ol = leg.peg_precision(tsl, G5)
+            Kl = Rl + A5
+            t_a = _time_cuda(lambda: leg.peg_precision(tsl, G5), 5)
+            t_m = _time_cuda(lambda: cr.mahal_and_det(Kl, Ol, vl), 10)
+            f_m, f_l = leg.leg_mahal_and_det(tsl, G5, A5, vl)
+            u_m, u_l = cr.mahal_and_det(Kl, Ol, vl)
+            out["leg_fused_N2^20_rank5_regular_grid"] = {
+                "fused_us": t_f * 1e6, "unfused_assembly_us": t_a * 1e6, "unfused_mahal_and_det_us": t_m * 1e6,
+                "hbm_bytes_read_by_the_fused_launch_algorithmic": nl * 8 * (1 + G5.shape[0]),
+                "logdet_rel_diff_fused_vs_unfused": abs(float(f_l) - float(u_l)) / abs(float(u_l)),
+                "mahal_rel_diff_fused_vs_unfused": abs(float(f_m) - float(u_m)) / abs(float(u_m))}
+            del Rl, Ol, Kl, tsl, vl
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["leg_fused_N2^20_rank5_regular_grid"] = {"error": repr(e)[:200]}
+        finally:
+            cr.CHECK_POSITIVE_DEFINITE = True
     except Exception as e:
         out["c5_leg_co2like"] = {"error": repr(e)[:200]}
     return out

@@ -78,6 +78,36 @@ int cgps_finish_records(const void* records, size_t record_stride_bytes, const d
   });
 }
 
+int cgps_leg_mahal_logdet(const void* ts, const void* G, const void* A, const void* v, int64_t N, int d, int dtype, void* ws,
+                          size_t ws_bytes, double* out2, int* info, void* stream) {
+  if (bad_common(N, d) || !ts || !G || !ws || !out2 || !info)
+    return fail(CGPS_ERR_ARG, "cgps_leg_mahal_logdet: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const int rc = cgps::run_tile_leg<T, D>((const T*)ts, (const T*)G, (const T*)A, (const T*)v, N, (char*)ws, ws_bytes, out2,
+                                            info, (hipStream_t)stream);
+    if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_leg_mahal_logdet");
+    if (rc == -2) return fail(CGPS_ERR_UNSUPPORTED, "cgps_leg_mahal_logdet: not built for this block size (d = 8, fp64 d = 6) or CGPS_NO_FOLD=1");
+    return check_launch("LEG tile reduction");
+  });
+}
+
+int cgps_leg_mahal_logdet_pair(const void* ts, const void* G, const void* A, const void* v, int64_t N, int d, int dtype,
+                               void* ws, size_t ws_bytes, double* out4, int* info2, void* stream) {
+  if (bad_common(N, d) || !ts || !G || !ws || !out4 || !info2)
+    return fail(CGPS_ERR_ARG, "cgps_leg_mahal_logdet_pair: null pointer or N < 1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    const int rc = cgps::run_tile_leg<T, D>((const T*)ts, (const T*)G, (const T*)A, (const T*)v, N, (char*)ws, ws_bytes, out4,
+                                            info2, (hipStream_t)stream, true);
+    if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_leg_mahal_logdet_pair (twice cgps_mahal_logdet's, each rounded up to 256 bytes)");
+    if (rc == -2) return fail(CGPS_ERR_UNSUPPORTED, "cgps_leg_mahal_logdet_pair: not built for this block size (d = 8, fp64 d = 6) or CGPS_NO_FOLD=1");
+    return check_launch("LEG tile reduction (pair)");
+  });
+}
+
 int cgps_reset_counters(void* stream) {
   if (cgps::fold_reset_counters((hipStream_t)stream) != hipSuccess) return check_launch("cgps_reset_counters");
   return CGPS_OK;

@@ -42,8 +42,10 @@
 
 #include "cgps_level.h"
 #include "cgps_tile_sizes.h"
+#include "cgps_leg.h"
 
 namespace cgps {
+#include "cgps_tile_leg.h"
 
 // ---- LDS tile of NTILE block rows ------------------------------------------------------
 //   R[NTILE][DD], y[NTILE][D] : the rows; a slot whose row has been eliminated is reused for
@@ -713,6 +715,8 @@ struct FoldArgs {
   void* shard_record;              // ... or one shard of a larger system (non-null): its single record
   double* shard_partial;           //     and its {sum of squares, sum of log pivots, fail, 0}
   int rows_per_lane;               // chunk_reduce_kernel<.., C = 0, ..>: rows per lane given at run time (a multiple of 4)
+  int pair_slot;                   // SRC = 1, gridDim.y = 2: counters and workspace offset (bytes) of the second system
+  size_t pair_ws_stride;
 };
 template <typename T, int D, int NTILE, int NT, bool FINAL, bool INL = false>
 __device__ __forceinline__ void record_reduce_body(char* smem, unsigned tile_index, const T* __restrict__ rin, int64_t n,
@@ -803,7 +807,9 @@ __device__ __forceinline__ void fold_record_stages(char* smem, int* last_flag, T
 // one round of the chip at the compiled C is still ONE round then -- every lane simply walks a longer chunk -- so
 // the serial tail (in-LDS levels, record stages) is paid once per launch instead of once per round, and nothing
 // but the last round's tail of a multi-round grid ever had the memory system to itself anyway.
-template <typename T, int D, int CT, int NT, int NW = NT, bool FOLD = false>
+// SRC = 1: the rows are those of a LEG model, assembled in registers (cgps_tile_leg.h): Rg = time stamps [N], Og = the
+// generator G [d][d], Oleft = the block A added to every diagonal block (or nullptr), yg = right-hand side (or nullptr).
+template <typename T, int D, int CT, int NT, int NW = NT, bool FOLD = false, int SRC = 0>
 __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void chunk_reduce_kernel(const T* __restrict__ Rg, const T* __restrict__ Og,
                                                           const T* __restrict__ yg, int64_t N,
                                                           const T* __restrict__ Oleft,
@@ -818,6 +824,21 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   CGPS_KSTAMP(0);
   if (tid == 0) *sm.sfail = 0x7fffffff;
   const int C = CT > 0 ? CT : fold.rows_per_lane;
+  if constexpr (SRC == 1) {
+    // a pair launch (gridDim.y = 2: the two reductions of a LEG log-likelihood, models.py:349-367, side by side):
+    // blockIdx.y = 1 is the prior precision itself -- no diagonal term, no right-hand side -- with its own records,
+    // partial results, counters and outputs (out2 + 2, info + 1)
+    if (blockIdx.y == 1) {
+      Oleft = nullptr;
+      yg = nullptr;
+      rec = reinterpret_cast<T*>(reinterpret_cast<char*>(rec) + fold.pair_ws_stride);
+      partial = reinterpret_cast<double*>(reinterpret_cast<char*>(partial) + fold.pair_ws_stride);
+      fold.group_records = reinterpret_cast<char*>(fold.group_records) + fold.pair_ws_stride;
+      fold.slot = fold.pair_slot;
+      fold.out2 += 2;
+      fold.info += 1;
+    }
+  }
   const int64_t lane0 = (int64_t)blockIdx.x * NT;
   const int64_t gl = lane0 + tid;
   int64_t r0 = gl * C, rE = gl * C + C;                         // this lane's chunk [r0, rE)
@@ -842,7 +863,7 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   // is fetched again (PMC: 1.15 x the algorithmic bytes leave L2 that way).  Such lanes copy the
   // whole line into their 128 bytes of the (still idle) LDS tile when they reach it.
   constexpr int YR = 4;
-  constexpr bool YSTAGE = std::is_same<T, double>::value && D == 4 && (CT == 0 || (CT >= YR && CT % YR == 0));
+  constexpr bool YSTAGE = SRC == 0 && std::is_same<T, double>::value && D == 4 && (CT == 0 || (CT >= YR && CT % YR == 0));
   T* ylds = reinterpret_cast<T*>(smem) + (size_t)tid * (YR * D);
   const bool yfull = YSTAGE && whole_chunk && r0 < N;      // the lane's chunk is complete: whole lines exist
   auto stage_y_line = [&](int64_t row) {                   // rows row .. row+YR-1 -> this lane's LDS line
@@ -855,8 +876,21 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
     }
   };
   constexpr int RG = stage1_row_group<T, D>();
-  constexpr bool GROUPED = RG > 1 && CT % RG == 0 && !YSTAGE;
+  constexpr bool GROUPED = SRC == 0 && RG > 1 && CT % RG == 0 && !YSTAGE;
   const bool grouped = GROUPED && whole_chunk_and_next && r0 < N;   // every row of the chunk, and O[last row], exist
+  T cR[D][D], cB[D][D];                          // SRC = 1: what the gap before the next row leaves it (cgps_tile_leg.h)
+  if constexpr (SRC == 1) {
+    if (r0 < N) {
+      if (r0 >= 1) {
+        T tl[D][D];
+        if (!leg_gap<T, D>(Rg, Og, r0 - 1, cR, tl, cB)) fail = true;
+      } else {
+        set_zero<T, D>(cR);
+        set_zero<T, D>(cB);
+      }
+      leg_row<T, D>(Rg, Og, Oleft, yg, r0, N, cR, cB, Rc, Cc, yc, fail);
+    }
+  } else
   if (r0 < N) {
     if (!grouped) {
       load_block<T, D>(Rg + r0 * DD, Rc);
@@ -917,6 +951,11 @@ __global__ __launch_bounds__(NW, (NW > NT ? 1 : stage1_min_waves<T, D>())) void 
   for (int j = 0; j < L - 1; ++j) {
     const int64_t rn = r0 + j + 1;
     T Rn[D][D], On[D][D], yn[D];
+    if constexpr (SRC == 1) {
+      leg_row<T, D>(Rg, Og, Oleft, yg, rn, N, cR, cB, Rn, On, yn, fail);
+      eliminate_forward<T, D>(Rc, yc, Cc, dRa, dya, On, Rn, yn, pl, mah, fail);
+      continue;
+    }
     load_block<T, D>(Rg + rn * DD, Rn);
     load_block<T, D>(Og + (rn - 1) * DD, On);
     if (yfull) {
@@ -1267,8 +1306,12 @@ void tile_set_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, Cfg::NT1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, 0, Cfg::NT1, Cfg::NT1, true, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chunk_reduce_kernel<T, D, Cfg::C, Cfg::NT1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
@@ -1556,6 +1599,50 @@ int run_tile_mahal_logdet(const T* Rs, const T* Os, const T* x, int64_t N, char*
                      (const T*)rin, n, rc, (T*)nullptr, (double*)nullptr, (const double*)partial, npart, out2, info,
                      rows_per_record, N, (int64_t)RL::STRIDE, (int64_t)PARTIAL_STRIDE);
   return 0;
+}
+
+// The same pipeline with the operands of a LEG model assembled in registers (chunk_reduce_kernel<.., SRC = 1>,
+// cgps_tile_leg.h): J = PEG precision(ts, G) + blockdiag(A), right-hand side v (nullptr: zeros).  ONE launch at any
+// size: the rows per lane are chosen at launch so that the grid is one round of at most 256 workgroups -- one row per
+// lane up to 65 536 rows, where what counts is the length of a lane's chain of matrix exponentials.
+// Built for the block sizes whose stage 1 runs one lane per row (every d <= 7 but fp64 d = 6).
+// returns 0 on success, -1 when the workspace is too small, -2 when this (dtype, d) is not built
+template <typename T, int D> constexpr bool leg_source_supported() { return TileCfg<T, D>::LPR == 1; }
+template <typename T, int D>
+int run_tile_leg(const T* ts, const T* G, const T* A, const T* v, int64_t N, char* ws, size_t ws_bytes, double* out2,
+                 int* info, hipStream_t st, bool pair = false) {
+  if constexpr (!leg_source_supported<T, D>()) {
+    return -2;
+  } else {
+    using Cfg = TileCfg<T, D>;
+    using RL = RecordLayout<T, D>;
+    if (!fold_final_enabled()) return -2;
+    const size_t ws1 = (tile_ws_bytes(N, D, sizeof(T)) + 255) & ~(size_t)255;
+    if (ws_bytes < (pair ? 2 * ws1 : ws1)) return -1;
+    const int64_t per_round = (int64_t)STAGE1_SMALL_TILES * Cfg::NG1;
+    const int64_t c = (N + per_round - 1) / per_round;
+    if (c > (1 << 20)) return -2;
+    const int64_t rows_per_tile = c * Cfg::NG1;
+    const int64_t tiles = (N + rows_per_tile - 1) / rows_per_tile;
+    const int64_t tiles_cap = tile_cap(N, D, sizeof(T));
+    double* partial = reinterpret_cast<double*>(ws);
+    const size_t pbytes = ((size_t)(2 * tiles_cap + 8) * PARTIAL_STRIDE * sizeof(double) + 255) & ~(size_t)255;
+    T* recA = reinterpret_cast<T*>(ws + pbytes);
+    T* recB = recA + (size_t)(tiles_cap + 2) * RL::STRIDE;
+    tile_set_attributes<T, D>();
+    const FoldArgs fa{fold_slot_for(ws), recB, out2, info, nullptr, nullptr, (int)c, pair ? fold_slot_for(ws + ws1) : 0, ws1};
+    const dim3 grid((unsigned)tiles, pair ? 2u : 1u);
+    if constexpr (Cfg::ALWAYS_WIDE) {
+      const size_t ldsw = stage_lds_bytes<T, D>(Cfg::NG1, 2 * Cfg::NT1);
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 0, Cfg::NT1, 2 * Cfg::NT1, true, 1>), grid, dim3(2 * Cfg::NT1), ldsw, st, ts,
+                         G, v, N, A, recA, partial, fa);
+    } else {
+      const size_t lds1 = stage_lds_bytes<T, D>(Cfg::NG1, Cfg::NT1);
+      hipLaunchKernelGGL((chunk_reduce_kernel<T, D, 0, Cfg::NT1, Cfg::NT1, true, 1>), grid, dim3(Cfg::NT1), lds1, st, ts, G, v,
+                         N, A, recA, partial, fa);
+    }
+    return 0;
+  }
 }
 
 // Finish a sharded reduction: P shard records (in shard order) + their partial results ->

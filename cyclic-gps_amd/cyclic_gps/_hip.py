@@ -39,6 +39,8 @@ _SIGNATURES = {
     "cgps_inverse_blocks": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "cgps_mahal_logdet_adjoint": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp]),
     "cgps_peg_precision": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp]),
+    "cgps_leg_mahal_logdet": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
+    "cgps_leg_mahal_logdet_pair": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "cgps_peg_precision_adjoint": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "cgps_leg_intercast": (_int, [_vp, _i64, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgps_record_elems": (_int, [_int, _int, ctypes.POINTER(_i64)]),

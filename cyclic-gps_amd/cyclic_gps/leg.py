@@ -23,6 +23,18 @@ import torch
 from . import cyclic_reduction as cr
 
 
+_eyes = {}
+
+
+def _scaled_eye(n, scale, dtype, device):
+    """scale * I, built once per (n, scale, dtype, device): N ~ 500 is launch-bound and this is two launches per use."""
+    key = (n, scale, dtype, device)
+    e = _eyes.get(key)
+    if e is None:
+        e = _eyes[key] = scale * torch.eye(n, dtype=dtype, device=device)
+    return e
+
+
 class LEGMatrices:
     """The four model matrices as the reference registers them (models.py:135-178):
     N [d,d] lower triangular, R [d,d] strictly lower (G uses R - R^T), B [obs,d],
@@ -37,21 +49,25 @@ class LEGMatrices:
     @property
     def G(self):
         d = self.N.shape[0]
-        return self.N @ self.N.T + self.R - self.R.T + 1e-5 * torch.eye(d, dtype=self.N.dtype, device=self.N.device)
+        return torch.addmm(self.R - self.R.T + _scaled_eye(d, 1e-5, self.N.dtype, self.N.device), self.N, self.N.T)
 
     @property
     def LLT_inv(self):
         """(Lambda Lambda^T + 1e-9 I)^-1, obs_dim x obs_dim, used through plain matrix products
         (torch.linalg.solve's GPU backward faults on ROCm 7.0 for a 1x1 system with hundreds of
         right-hand sides; the inverse's backward is matmul only)."""
-        if self.Lambda.shape[0] == 1:                 # a single output: no factorisation call (and none inside a HIP graph)
-            return 1.0 / self.LLT
-        return torch.linalg.inv_ex(self.LLT)[0]       # inv_ex: no error check, hence no device->host synchronisation
+        return self.inv_of(self.LLT)
+
+    @staticmethod
+    def inv_of(LLT):
+        if LLT.shape[0] == 1:                         # a single output: no factorisation call (and none inside a HIP graph)
+            return 1.0 / LLT
+        return torch.linalg.inv_ex(LLT)[0]            # inv_ex: no error check, hence no device->host synchronisation
 
     @property
     def LLT(self):
         o = self.Lambda.shape[0]
-        return self.Lambda @ self.Lambda.T + 1e-9 * torch.eye(o, dtype=self.Lambda.dtype, device=self.Lambda.device)
+        return torch.addmm(_scaled_eye(o, 1e-9, self.Lambda.dtype, self.Lambda.device), self.Lambda, self.Lambda.T)
 
 
 def _peg_precision_hip(ts, G):
@@ -132,6 +148,68 @@ def peg_precision(ts, G):
     return Rs.contiguous(), (-b).contiguous()
 
 
+def fused_supported(ts, G):
+    """The assembly-in-registers form (cgps_leg_mahal_logdet) exists for this case: GPU tensors, no gradient wanted, a
+    block size whose first pass runs one lane per row."""
+    d = G.shape[0]
+    return (G.is_cuda and ts.is_cuda and G.dtype in (torch.float32, torch.float64) and 1 <= d <= 7 and
+            not (d == 6 and G.dtype == torch.float64) and
+            not (torch.is_grad_enabled() and (G.requires_grad or ts.requires_grad)) and
+            os.environ.get("CGPS_LEG_UNFUSED") != "1")
+
+
+def leg_mahal_and_det(ts, G, A=None, v=None):
+    """(v^T J^-1 v, log|J|) of J = PEG precision(ts, G) + blockdiag(A) in ONE kernel launch that never writes the blocks
+    of J to memory (cgps_leg_mahal_logdet, csrc/cgps_tile_leg.h): what `peg_precision` + `cr.mahal_and_det` compute
+    (models.py:349-367).  A [d,d] or None; v [N,d] or None (zeros).  No autograd graph."""
+    from . import _hip
+    n, d, dt = ts.shape[0], G.shape[0], G.dtype
+    ts = ts.to(dt).contiguous()
+    G = G.contiguous()
+    A = None if A is None else A.to(dt).contiguous()
+    v = None if v is None else v.to(dt).contiguous()
+    ws, ws_bytes = _hip.workspace(n, d, dt, _hip.OP_MAHAL_LOGDET, G.device)
+    out = torch.empty(2, dtype=torch.float64, device=G.device)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    _hip.check(_hip.lib().cgps_leg_mahal_logdet(_hip.ptr(ts), _hip.ptr(G), _hip.ptr(A), _hip.ptr(v), n, d, _hip.dtype_code(dt),
+                                                _hip.ptr(ws), ws_bytes, _hip.ptr(out), _hip.ptr(info), _hip.stream_ptr()))
+    if cr.CHECK_POSITIVE_DEFINITE:
+        bad = int(info.item())
+        if bad:
+            raise cr.NotPSDError("LEG system: a block near row %d is not positive definite (or a time gap has zero length)" % (bad - 1))
+    out = out.to(dt)
+    return out[0], out[1]
+
+
+_pair_ws = {}
+
+
+def leg_loglik_reductions(ts, G, A, v):
+    """The two reductions of a LEG log-likelihood in ONE launch (cgps_leg_mahal_logdet_pair): returns
+    (v^T K^-1 v, log|K|, log|Sigma^-1|) with K = PEG precision(ts, G) + blockdiag(A), Sigma^-1 the PEG precision itself
+    (models.py:349-367: decompose + det of Sigma^-1, mahal_and_det of K).  No autograd graph."""
+    from . import _hip
+    n, d, dt = ts.shape[0], G.shape[0], G.dtype
+    ts = ts.to(dt).contiguous()
+    G, A, v = G.contiguous(), A.to(dt).contiguous(), v.to(dt).contiguous()
+    nbytes = 2 * ((_hip._workspace_bytes(int(n), int(d), _hip.dtype_code(dt), _hip.OP_MAHAL_LOGDET) + 255) // 256 * 256)
+    key = (G.device, torch.cuda.current_stream().cuda_stream)
+    ws = _pair_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _pair_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=G.device)
+    out = torch.empty(4, dtype=torch.float64, device=G.device)
+    info = torch.zeros(2, dtype=torch.int32, device=G.device)
+    _hip.check(_hip.lib().cgps_leg_mahal_logdet_pair(_hip.ptr(ts), _hip.ptr(G), _hip.ptr(A), _hip.ptr(v), n, d, _hip.dtype_code(dt),
+                                                     _hip.ptr(ws), ws.numel(), _hip.ptr(out), _hip.ptr(info), _hip.stream_ptr()))
+    if cr.CHECK_POSITIVE_DEFINITE:
+        bad = info.tolist()
+        if bad[0] or bad[1]:
+            raise cr.NotPSDError("LEG system: a block near row %d is not positive definite (or a time gap has zero length)"
+                                 % ((bad[0] or bad[1]) - 1))
+    out = out.to(dt)
+    return out[0], out[1], out[3]
+
+
 def posterior_precision(m, ts):
     Rs, Os = peg_precision(ts, m.G)
     BtLB = m.B.T @ m.LLT_inv @ m.B
@@ -145,12 +223,18 @@ def compute_v(m, xs):
 def log_likelihood(m, ts, xs):
     """log p(xs | ts) of the LEG model (models.py:301-372)."""
     LLT = m.LLT
-    Li = m.LLT_inv
+    Li = m.inv_of(LLT)
     xl = xs @ Li
     llt_mahal = (xl * xs).sum()
     llt_det = (torch.log(2 * math.pi * LLT[0, 0]) if LLT.shape[0] == 1 else torch.logdet(2 * math.pi * LLT)) * xs.shape[0]
     v = (xl @ m.B).contiguous()
-    Rs, Os = peg_precision(ts, m.G)
+    G = m.G
+    if fused_supported(ts, G):
+        # the two reductions (prior precision: log-det only; posterior precision: mahal + log-det) never see their blocks
+        # in memory, and run side by side in one launch: they share nothing but ts and G
+        k_mahal, k_det, sig_inv_det = leg_loglik_reductions(ts, G, m.B.T @ Li @ m.B, v)
+        return -0.5 * ((llt_mahal - k_mahal) + (llt_det + k_det - sig_inv_det))
+    Rs, Os = peg_precision(ts, G)
     _, sig_inv_det = cr.mahal_and_det(Rs, Os, torch.zeros_like(v))       # = det(decompose(Rs, Os)), fused
     K_Rs = Rs + (m.B.T @ Li @ m.B).unsqueeze(0)
     k_mahal, k_det = cr.mahal_and_det(Rs=K_Rs, Os=Os, x=v)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CGPS_VERSION 300
+#define CGPS_VERSION 310
 
 enum { CGPS_F32 = 0, CGPS_F64 = 1 };
 
@@ -140,6 +140,25 @@ int cgps_mahal_logdet_adjoint(void* Sd, void* So, const void* w, int64_t N, int 
  * (zero-length gap, NaN).  No workspace. */
 int cgps_peg_precision(const void* ts, const void* G, int64_t N, int d, int dtype,
                        void* Rs, void* Os, int* info, void* stream);
+
+/* cgps_mahal_logdet of a LEG system WITHOUT materialising its blocks (the assembly fused into the first pass of the
+ * reduction; replaces cgps_peg_precision + cgps_mahal_logdet of models.py:349-367 when no factor is kept):
+ *     J = PEG precision(ts, G) + blockdiag(A),   out2 = {v^T J^-1 v, log|J|}
+ * ts[N], G[d][d], A[d][d] (added to EVERY diagonal block; NULL: nothing added -- the prior precision itself),
+ * v[N][d] (NULL: zeros, out2[0] = 0).  Every lane assembles the block rows it eliminates in registers from the time
+ * stamps: nothing but ts and v is read from HBM.  One launch at any N.  Workspace, out2 and info as for
+ * cgps_mahal_logdet (cgps_workspace_bytes(N, d, dtype, CGPS_OP_MAHAL_LOGDET)); info also reports a singular gap
+ * (zero length).  CGPS_ERR_UNSUPPORTED for d = 8 and fp64 d = 6 (their first pass shares a block row between lanes):
+ * assemble with cgps_peg_precision and call cgps_mahal_logdet there. */
+int cgps_leg_mahal_logdet(const void* ts, const void* G, const void* A, const void* v, int64_t N, int d, int dtype,
+                          void* ws, size_t ws_bytes, double* out2, int* info, void* stream);
+
+/* Both reductions of a LEG log-likelihood (models.py:349-367) in ONE launch, side by side:
+ *   out4[0..1] = {v^T K^-1 v, log|K|},  K = PEG precision(ts, G) + blockdiag(A)      (posterior precision, info2[0])
+ *   out4[2..3] = {0, log|PEG precision(ts, G)|}                                       (prior precision,     info2[1])
+ * Workspace: twice cgps_workspace_bytes(N, d, dtype, CGPS_OP_MAHAL_LOGDET), each half rounded up to 256 bytes. */
+int cgps_leg_mahal_logdet_pair(const void* ts, const void* G, const void* A, const void* v, int64_t N, int d, int dtype,
+                               void* ws, size_t ws_bytes, double* out4, int* info2, void* stream);
 
 /* Adjoint of cgps_peg_precision in G and in the time gaps (training through the assembly; what
  * autograd computes through models.py:181-239 for LEGFamily.training_step, models.py:374-381).
