@@ -231,6 +231,11 @@ def extra_measurements(dev):
                 t_det = _time_cuda(lambda: cr.det(holder["dec"]), reps)
                 t_inv = _time_cuda(lambda: cr.inverse_blocks(holder["dec"]), max(2, reps // 3))
                 xs = cr.solve(holder["dec"], b)
+                # factor and solve in one call (cgps_decompose_solve: the forward substitution rides along in the first
+                # pass of the factorisation, the factor is read once instead of twice)
+                t_ds = _time_cuda(lambda: cr.decompose_solve(Rs, Os, b), reps)
+                res.update(decompose_solve_us=t_ds * 1e6, factor_solves_per_s_one_call=1.0 / t_ds,
+                           decompose_solve_max_abs_err=float((cr.decompose_solve(Rs, Os, b)[1].double() - x_true.double()).abs().max()))
                 res.update(decompose_us=t_dec * 1e6, solve_us=t_sol * 1e6, det_us=t_det * 1e6,
                            inverse_blocks_us=t_inv * 1e6,
                            decompose_GBps=5.0 * n * d * d * s / t_dec / 1e9,

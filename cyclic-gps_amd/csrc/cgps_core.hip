@@ -68,6 +68,15 @@ int cgps_workspace_bytes(int64_t N, int d, int dtype, int op, size_t* bytes) {
       *bytes = crr + m;
       return CGPS_OK;
     }
+    case CGPS_OP_DECOMPOSE_SOLVE: {
+      size_t a = 0, b = 0, c = 0;
+      (void)cgps_workspace_bytes(N, d, dtype, CGPS_OP_DECOMPOSE, &a);
+      (void)cgps_workspace_bytes(N, d, dtype, CGPS_OP_HALFSOLVE, &b);
+      (void)cgps_workspace_bytes(N, d, dtype, CGPS_OP_BACKSOLVE, &c);
+      const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+      *bytes = align_up(m) + decompose_solve_tail_bytes(N, d, s);
+      return CGPS_OK;
+    }
     case CGPS_OP_LOGDET_FACTOR:
       *bytes = align_up((size_t)(1024 + 2) * 16);
       return CGPS_OK;

@@ -138,13 +138,34 @@ __device__ __forceinline__ void store_blocks_coalesced(T* stage, T* __restrict__
 // The single tile of the last pass (rec_out == nullptr) runs lv.nlev <= DEC_MAXLEV levels until
 // nothing is left; otherwise lv.nlev <= 7 levels, then the surviving rows go to rec_out
 // (tile t, survivor m -> record t * (DEC_TS >> lv.nlev) + m; a tile's first record also carries DRA).
-template <typename T, int D, bool FROM_RECORDS>
+// RHS (first pass of cgps_decompose_solve, FROM_RECORDS = false): the forward substitution of a right-hand side rides
+// along -- x = D^-1 y of every eliminated row goes to xcrr (the layout of halfsolve, cyclic_reduction.py:312-338: level
+// by level, elimination index within the level), the odd rows take y -= F x + G x' exactly where their blocks take
+// -F F^T - G G^T, the surviving rows' y goes to ynext[tile * survivors + m] and what the tile's first eliminations owe
+// the previous tile's last row to owedy[tile] (decomp_rhs_fixup_kernel adds it).  The forward sweep of a later solve
+// then starts at the level this pass stops at: it never reads the factor blocks of the levels done here.
+template <typename T>
+__device__ __forceinline__ T shfl_one(T v, int src) { return __shfl(v, src, 64); }
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decomp_rhs_fixup_kernel(T* __restrict__ ynext, const T* __restrict__ owedy, int64_t ntiles,
+                                                               int spt_out, int64_t n_next) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (tile t >= 1, component) pairs
+  const int64_t t = i / D + 1;
+  const int c = (int)(i % D);
+  if (t >= ntiles) return;
+  const int64_t row = t * spt_out - 1;                              // last survivor of tile t - 1
+  if (row < n_next) ynext[row * D + c] += owedy[t * D + c];
+}
+template <typename T, int D, bool FROM_RECORDS, bool RHS = false>
 __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_tile_kernel(const T* __restrict__ Rin, const T* __restrict__ Oin,
                                                              int64_t n, int64_t n_rec, int spt_in, DecompLevels lv,
                                                              int lvl_first,
                                                              T* __restrict__ Dp, T* __restrict__ Fp,
                                                              T* __restrict__ Gp, T* __restrict__ rec_out,
-                                                             int* __restrict__ info) {
+                                                             int* __restrict__ info, const T* __restrict__ yin = nullptr,
+                                                             T* __restrict__ xcrr = nullptr, T* __restrict__ ynext = nullptr,
+                                                             T* __restrict__ owedy = nullptr) {
+  static_assert(!RHS || !FROM_RECORDS, "the right-hand side rides along in the first pass only");
   constexpr int DD = D * D;
   using RL = RecordLayout<T, D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,10 +205,37 @@ __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_til
     const int n0 = (int)((n - row0) < DEC_TS ? (n - row0) : DEC_TS);
     auto report = [&](int slot_row) { report_fail(info, ((row0 + slot_row + 1) << lvl_first) - 1); };
     T Cc[D][D];                    // coupling of the row this lane carries (Rr) to the previous such row
-    T owed[D][D];                  // lane 0: minus what this tile owes the previous tile's last row
+    // lane 0: minus what this tile owes the previous tile's last row.  The plain kernel keeps it in registers (238, no
+    // scratch); with a right-hand side riding along those registers are what spills, so there lane 0 keeps it in LDS
+    // behind the staging buffer (one wave per workgroup: its LDS instructions execute in order)
+    T owed[RHS ? 1 : D][RHS ? 1 : D];
+    T* const owed_l = stage + 64 * DD;     // RHS: [DD] lower triangle, then [D] the vector part
     set_zero<T, D>(Cc);
-    set_zero<T, D>(owed);
+    if constexpr (RHS) {
+      if (lane < DD + D) owed_l[lane] = T(0);
+      if (DD + D > 64 && lane + 64 < DD + D) owed_l[lane + 64] = T(0);
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) owed[a][b] = T(0);
+    }
+    auto owe = [&](const T (&U)[D][D]) {   // lane 0 only
+      if constexpr (RHS) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) owed_l[a * D + b] -= U[a][b];
+      } else {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) owed[a][b] -= U[a][b];
+      }
+    };
     int levels = 0;
+    T yr[D];                       // RHS: right-hand side of the row this lane carries
+    set_zero<T, D>(yr);
 
     // ---- level 0: lane k eliminates row 2k; row 2k+1 (if any) is the lane's level-1 row k -----
     {
@@ -209,23 +257,45 @@ __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_til
         }
         store_blocks_coalesced<T, D>(stage, Dp + (lv.offD[0] + ge0) * DD, L, act, lane, cntD, 0);
       }
+      T x[D], gy[D];
+      set_zero<T, D>(x);
+      set_zero<T, D>(gy);
       if (act) {
         rsolve_lt_transposed<T, D>(c, Cl, G);                      // G = J[2k, 2k-1]^T D^-T
         syrk_lower<T, D>(UL, G);                                   // owed to row 2k-1
+        if constexpr (RHS) {
+          load_vec<T, D>(yin + (row0 + 2 * lane) * D, x);
+          fwd_subst<T, D>(c, x);                                   // x = D^-1 y
+          store_vec<T, D>(xcrr + (lv.offD[0] + ge0 + lane) * D, x);
+#pragma unroll
+          for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) gy[a] = fmaT(G[a][b], x[b], gy[a]);
+        }
       }
       store_blocks_coalesced<T, D>(stage, Gp + (lv.offG[0] + ge0 - 1) * DD, G, act, lane, cntD, ge0 == 0 ? 1 : 0);
       if (has_o) load_row(row0 + 2 * lane + 1, Rr, Cm);
+      if constexpr (RHS) {
+        if (has_o) load_vec<T, D>(yin + (row0 + 2 * lane + 1) * D, yr);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const T v = shfl_one<T>(gy[a], lane + 1);                // G x of row 2k+2, owed to row 2k+1
+          if (has_o && 2 * lane + 2 < n0) yr[a] -= v;
+          if (lane == 0) owed_l[DD + a] -= gy[a];
+        }
+      }
       {
         T U[D][D];
         shfl_lower<T, D>(U, UL, lane + 1);                         // what row 2k+2 owes row 2k+1
         if (has_o && 2 * lane + 2 < n0) sub_lower<T, D>(Rr, U);
       }
-      if (lane == 0) sub_lower<T, D>(owed, UL);
+      if (lane == 0) owe(UL);
       if (has_o) rsolve_lt<T, D>(c, Cm);                           // F = J[2k+1, 2k] D^-T
       store_blocks_coalesced<T, D>(stage, Fp + (lv.offF[0] + ge0) * DD, Cm, has_o, lane, cntF, 0);
       if (has_o) {
         syrk_sub_lower<T, D>(Rr, Cm);
         neg_abt<T, D>(Cc, Cm, G);                                  // J'[2k+1, 2k-1] = -F G^T
+        if constexpr (RHS) gemv_sub<T, D>(yr, Cm, x);              // y_{2k+1} -= F x
       }
       levels = 1;
     }
@@ -259,9 +329,31 @@ __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_til
         }
         store_blocks_coalesced<T, D>(stage, Dp + (lv.offD[j] + ge0) * DD, L, even, m >> 1, cntD, 0);
       }
+      T x[D], gy[D];
+      set_zero<T, D>(x);
+      set_zero<T, D>(gy);
       if (even) {
         rsolve_lt_transposed<T, D>(c, Cc, G);
         syrk_lower<T, D>(U, G);                                    // owed to row m-1
+        if constexpr (RHS) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) x[a] = yr[a];
+          fwd_subst<T, D>(c, x);
+          store_vec<T, D>(xcrr + (lv.offD[j] + ge0 + (m >> 1)) * D, x);
+#pragma unroll
+          for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) gy[a] = fmaT(G[a][b], x[b], gy[a]);
+        }
+      }
+      if constexpr (RHS) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const T v = shfl_one<T>(gy[a], lane + st);               // G x of row m+1, owed to row m
+          if (odd && m + 1 < M) yr[a] -= v;
+          const T v0 = shfl_one<T>(gy[a], st - 1);                 // the tile's first elimination: owed to the previous tile
+          if (lane == 0) owed_l[DD + a] -= v0;
+        }
       }
       store_blocks_coalesced<T, D>(stage, Gp + (lv.offG[j] + ge0 - 1) * DD, G, even, m >> 1, cntD, ge0 == 0 ? 1 : 0);
       {
@@ -269,12 +361,27 @@ __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_til
         shfl_lower<T, D>(V, U, lane + st);
         if (odd && m + 1 < M) sub_lower<T, D>(Rr, V);
         shfl_lower<T, D>(V, U, st - 1);                            // the tile's first elimination: owed to the previous tile
-        if (lane == 0) sub_lower<T, D>(owed, V);
+        if (lane == 0) owe(V);
       }
       set_zero<T, D>(U);
       if (has_o) rsolve_lt<T, D>(c, F);
       store_blocks_coalesced<T, D>(stage, Fp + (lv.offF[j] + ge0) * DD, F, has_o, m >> 1, cntF, 0);
       if (has_o) syrk_lower<T, D>(U, F);                           // owed to row m+1
+      if constexpr (RHS) {
+        T fy[D];
+        set_zero<T, D>(fy);
+        if (has_o) {
+#pragma unroll
+          for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) fy[a] = fmaT(F[a][b], x[b], fy[a]);
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const T v = shfl_one<T>(fy[a], lane - st);               // F x of row m-1, owed to row m
+          if (odd) yr[a] -= v;
+        }
+      }
       {
         T V[D][D];
         shfl_lower<T, D>(V, U, lane - st);
@@ -307,10 +414,27 @@ __global__ __launch_bounds__(DEC_NT, (stage1_min_waves<T, D>())) void decomp_til
       T* r = rec_out + ((size_t)tile * spt_out + m) * RL::STRIDE;
       store_block<T, D>(r + RL::RS, Rr);
       store_block<T, D>(r + RL::CS, Cc);
+      if constexpr (RHS) store_vec<T, D>(ynext + ((size_t)tile * spt_out + m) * D, yr);
     }
     if (lane == 0) {
-      mirror_lower<T, D>(owed);
-      store_block<T, D>(rec_out + (size_t)tile * spt_out * RL::STRIDE + RL::DRA, owed);
+      if constexpr (RHS) {
+        T W[D][D], wy[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          wy[a] = owed_l[DD + a];
+#pragma unroll
+          for (int b = 0; b <= a; ++b) W[a][b] = W[b][a] = owed_l[a * D + b];
+        }
+        store_block<T, D>(rec_out + (size_t)tile * spt_out * RL::STRIDE + RL::DRA, W);
+        store_vec<T, D>(owedy + (size_t)tile * D, wy);
+      } else {
+        T W[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) W[a][b] = W[b][a] = owed[a][b];
+        store_block<T, D>(rec_out + (size_t)tile * spt_out * RL::STRIDE + RL::DRA, W);
+      }
     }
   };
 

@@ -15,7 +15,10 @@ namespace {
 template <int D> constexpr int64_t dec_small_rows() { return D == 8 ? 262144 : 32768; }   // at or below this many rows a pass is latency-bound
 template <typename T, int D>
 int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp, char* ws, size_t ws_bytes, int* info,
-                       hipStream_t st) {
+                       hipStream_t st, const T* y = nullptr, T* xcrr = nullptr, T* ynext = nullptr, T* owedy = nullptr,
+                       int* rhs_levels = nullptr) {
+  // y != nullptr (cgps_decompose_solve): the first pass, when it is a bulk pass of DEC_LP levels, also carries the
+  // forward substitution of y through its levels (decomp_tile_kernel<.., RHS = true>); *rhs_levels = levels done
   using RL = cgps::RecordLayout<T, D>;
   LevelWs w = level_ws(N, D, sizeof(T), true, false);
   if (ws_bytes < w.total) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, w.total);
@@ -84,7 +87,16 @@ int run_decompose_tile(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T* Gp,
     T* rout = top ? nullptr : recs[p & 1];
     const int64_t cap = grid_cap[p == 0 ? 0 : 1];
     const unsigned grid = (unsigned)(g < cap ? g : cap);
-    if (p == 0)
+    if (p == 0 && y != nullptr && !top && nl == cgps::DEC_LP) {
+      hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false, true>), dim3(grid), dim3(cgps::DEC_NT),
+                         lds + (size_t)(D * D + D) * sizeof(T), st, Rs, Os,
+                         rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info, y, xcrr, ynext, owedy);
+      const int64_t pairs = (g - 1) * D;
+      if (pairs > 0)
+        hipLaunchKernelGGL((cgps::decomp_rhs_fixup_kernel<T, D>), dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, ynext,
+                           (const T*)owedy, g, (int)(cgps::DEC_TS >> nl), L.ms[nl]);
+      if (rhs_levels) *rhs_levels = nl;
+    } else if (p == 0)
       hipLaunchKernelGGL((cgps::decomp_tile_kernel<T, D, false>), dim3(grid), dim3(cgps::DEC_NT), lds, st, Rs, Os,
                          rows, (int64_t)0, 1, dl, lvl, Dp, Fp, Gp, rout, info);
     else
@@ -184,6 +196,49 @@ int run_decompose_lds_only(const T* Rs, const T* Os, int64_t N, T* Dp, T* Fp, T*
 }  // namespace
 
 extern "C" {
+
+int cgps_decompose_solve(const void* Rs, const void* Os, const void* y, int64_t N, int d, int dtype, void* Dp, void* Fp,
+                         void* Gp, void* xcrr, void* x, void* ws, size_t ws_bytes, int* info, void* stream) {
+  if (bad_common(N, d) || !Rs || (N > 1 && !Os) || !y || !Dp || !Fp || !Gp || !xcrr || !x || !ws || !info)
+    return fail(CGPS_ERR_ARG, "cgps_decompose_solve: null pointer or N < 1");
+  size_t need = 0;
+  if (int rc = cgps_workspace_bytes(N, d, dtype, CGPS_OP_DECOMPOSE_SOLVE, &need)) return rc;
+  if (ws_bytes < need) return fail(CGPS_ERR_ARG, "workspace too small: %zu < %zu", ws_bytes, need);
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    // workspace: [what decompose / the sweeps need, one after the other] [ynext: (N/8 + 16) rows] [owedy: N/128 + 2 rows]
+    const size_t tail = decompose_solve_tail_bytes(N, D, sizeof(T));
+    const size_t main_bytes = ws_bytes - tail;
+    T* ynext = reinterpret_cast<T*>((char*)ws + main_bytes);
+    T* owedy = ynext + (size_t)(N / 8 + 16) * D;
+    int rhs_levels = 0, rc;
+    if constexpr (cgps::tile_fits_256<T, D>()) {
+      if (!levelwise_solve_requested())
+        rc = run_decompose_tile<T, D>((const T*)Rs, (const T*)Os, N, (T*)Dp, (T*)Fp, (T*)Gp, (char*)ws, main_bytes, info,
+                                      (hipStream_t)stream, (const T*)y, (T*)xcrr, ynext, owedy, &rhs_levels);
+      else
+        rc = cgps_decompose(Rs, Os, N, d, dtype, Dp, Fp, Gp, ws, main_bytes, info, stream);
+    } else {
+      rc = cgps_decompose(Rs, Os, N, d, dtype, Dp, Fp, Gp, ws, main_bytes, info, stream);
+    }
+    if (rc != CGPS_OK) return rc;
+    if (rhs_levels > 0) {
+      // the forward sweep goes on at level rhs_levels: the packed factor of levels >= l IS the packed factor of the
+      // (N >> l)-row system those levels reduce (level sizes halve with the same rounding), so the stored-factor
+      // sweep runs on that sub-system with the surviving rows' right-hand side
+      Layout L;
+      make_layout(N, L);
+      const int l = rhs_levels;
+      rc = cgps_halfsolve((const T*)Dp + L.offD[l] * D * D, (const T*)Fp + L.offF[l] * D * D, (const T*)Gp + L.offG[l] * D * D,
+                          L.ms[l], d, dtype, 1, ynext, (T*)xcrr + L.offD[l] * D, ws, main_bytes, nullptr, stream);
+    } else {
+      rc = cgps_halfsolve(Dp, Fp, Gp, N, d, dtype, 1, y, xcrr, ws, main_bytes, nullptr, stream);
+    }
+    if (rc != CGPS_OK) return rc;
+    return cgps_backsolve(Dp, Fp, Gp, N, d, dtype, 1, xcrr, x, ws, main_bytes, stream);
+  });
+}
 
 int cgps_decompose(const void* Rs, const void* Os, int64_t N, int d, int dtype, void* Dp, void* Fp, void* Gp, void* ws,
                    size_t ws_bytes, int* info, void* stream) {

@@ -137,6 +137,12 @@ LevelBuf<T> carve(char* base, int64_t cap, int d, bool with_mats, bool with_vec)
   return b;
 }
 
+// cgps_decompose_solve keeps the right-hand side of the rows that survive its first pass, and what each tile owes the
+// previous one, behind the workspace of the ops it runs one after the other
+inline size_t decompose_solve_tail_bytes(int64_t N, int d, size_t s) {
+  return align_up((size_t)(N / 8 + 16) * d * s) + align_up((size_t)(N / 128 + 2) * d * s);
+}
+
 inline bool bad_common(int64_t N, int d) { return N < 1 || d < 1; }
 
 inline bool levelwise_solve_requested() {

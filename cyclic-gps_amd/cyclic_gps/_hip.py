@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CGPS_LIB", os.path.join(os.path.dirname(_HERE), "lib"
 
 F32, F64 = 0, 1
 OP_MAHAL_LOGDET, OP_DECOMPOSE, OP_HALFSOLVE, OP_BACKSOLVE, OP_SOLVE, OP_LOGDET_FACTOR, OP_INVERSE_BLOCKS, \
-    OP_MAHAL_LOGDET_LEVELWISE = range(8)
+    OP_MAHAL_LOGDET_LEVELWISE, OP_DECOMPOSE_SOLVE = range(9)
 MAX_LEVELS = 64
 
 _lib = None
@@ -31,6 +31,7 @@ _SIGNATURES = {
     "cgps_mahal_logdet_levelwise": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),
     "cgps_decompose_step": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cgps_decompose": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "cgps_decompose_solve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cgps_solve_workspace_bytes": (_int, [_i64, _int, _int, _int, _int, ctypes.POINTER(_sz)]),
     "cgps_halfsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cgps_backsolve": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),

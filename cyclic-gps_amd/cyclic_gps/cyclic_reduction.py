@@ -189,6 +189,32 @@ def _decompose_raw(Rs, Os):
     return CRDecomp(ms, Ds, Fs, Gs, packed=(Dp, Fp, Gp), like=Rs)
 
 
+def decompose_solve(Rs, Os, y):
+    """(decompose(Rs, Os), solve(decomp, y)) in one call: what compute_insample_posterior does first
+    (reference models.py:288-292: decompose, then solve), with the forward substitution of y riding along in the
+    first pass of the factorisation -- the forward sweep never reads 7/8 of the factor (cgps_decompose_solve).
+    An addition to the reference's surface (its callers that factor and solve together can switch to it);
+    y: [N, d].  No autograd graph: with a gradient wanted, call decompose and solve."""
+    _check_blocks(Rs, Os)
+    N, d = Rs.shape[0], Rs.shape[1]
+    R, O = _stage(Rs.detach()), _stage(Os.detach())
+    dev, dt = R.device, R.dtype
+    v = _stage(y.detach()).to(dt).reshape(N, d).contiguous()
+    Dp, Fp, Gp = (torch.empty((N, d, d), dtype=dt, device=dev) for _ in range(3))
+    xcrr = torch.empty((N, d), dtype=dt, device=dev)
+    x = torch.empty((N, d), dtype=dt, device=dev)
+    info = torch.empty(1, dtype=torch.int32, device=dev)
+    ws, nbytes = _hip.workspace(N, d, dt, _hip.OP_DECOMPOSE_SOLVE, dev)
+    _hip.check(_hip.lib().cgps_decompose_solve(
+        _hip.ptr(R), _hip.ptr(O), _hip.ptr(v), N, d, _hip.dtype_code(dt), _hip.ptr(Dp), _hip.ptr(Fp), _hip.ptr(Gp),
+        _hip.ptr(xcrr), _hip.ptr(x), _hip.ptr(ws), nbytes, _hip.ptr(info), _hip.stream_ptr()))
+    _raise_if_not_pd(info, R, O)
+    ms, Ds, Fs, Gs = _views(Dp, Fp, Gp, N)
+    if Rs.device.type != "cuda":
+        Ds, Fs, Gs = ([_back(t, Rs) for t in lst] for lst in (Ds, Fs, Gs))
+    return CRDecomp(ms, Ds, Fs, Gs, packed=(Dp, Fp, Gp), like=Rs), _back(x.reshape(y.shape), y)
+
+
 def mahal_and_det(Rs, Os, x):
     """(x^T J^-1 x, log|J|) in one fused sweep, factor not kept   (reference :380-438).
     Differentiable in Rs, Os and x (the reference trains through it, models.py:367-381)."""
@@ -236,23 +262,12 @@ class _MahalLogdetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gm, gl):
         Rs, Os, x = ctx.saved_tensors
-        dec = _decompose_raw(Rs, Os)
         need_blocks = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         gR = gO = None
-        if need_blocks and Rs.is_cuda and Os.is_cuda and x.is_cuda:
-            # the solve (bandwidth-bound sweeps) and the selected inverse (latency-bound chain, one
-            # wave per SIMD) only share the factor: run them side by side on two streams
-            main, side = torch.cuda.current_stream(Rs.device), _side_stream(Rs.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
+        # factor and solve together: the forward substitution rides along in the factorisation (decompose_solve)
+        dec, w = decompose_solve(Rs, Os, x.reshape(Rs.shape[0], Rs.shape[1]))
+        if need_blocks:
             gR, gO = inverse_blocks(dec)
-            main.wait_stream(side)
-            w.record_stream(main)
-        else:
-            w = _solve_raw(dec, x).reshape(Rs.shape[0], Rs.shape[1])
-            if need_blocks:
-                gR, gO = inverse_blocks(dec)
         if need_blocks:
             # gR = gl Sigma_diag - gm w w^T, gO = 2 (gl Sigma_off - gm w[1:] w[:-1]^T), written over
             # the blocks inverse_blocks just produced (one pass instead of ten element-wise kernels)

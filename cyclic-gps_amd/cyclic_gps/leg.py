@@ -326,8 +326,12 @@ class GraphedValueAndGrad:
 def insample_posterior(m, ts, xs):
     """Posterior mean [N,d] and (diag, lower off-diag) covariance blocks (models.py:282-298)."""
     K_Rs, K_Os = posterior_precision(m, ts)
-    dec = cr.decompose(Rs=K_Rs, Os=K_Os)
-    mean = cr.solve(dec, compute_v(m, xs))
+    v = compute_v(m, xs)
+    if K_Rs.is_cuda and not (torch.is_grad_enabled() and (K_Rs.requires_grad or K_Os.requires_grad or v.requires_grad)):
+        dec, mean = cr.decompose_solve(K_Rs, K_Os, v)      # factor and solve together (cgps_decompose_solve)
+    else:
+        dec = cr.decompose(Rs=K_Rs, Os=K_Os)
+        mean = cr.solve(dec, v)
     return mean, cr.inverse_blocks(dec)
 
 

@@ -82,11 +82,11 @@ class ShardedMahalLogdet:
     run() returns a 2-element float64 tensor {x^T J^-1 x, log|J|}, identical on every rank.
 
     sub_shards = S > 1 cuts the rank's rows into S consecutive sub-shards, each reduced to its own
-    record by its own cgps_shard_reduce on its own HIP stream (the serial tail of one overlaps the
-    streaming of the next), and the ONE all-gather then carries S records per rank; the finish kernel
-    takes the world * S records in order.  Default: one record per rank -- a shard of more than one
-    round of the chip is already reduced by ONE launch whose workgroups overlap the in-LDS reduction
-    of a tile with the streaming of the next (csrc/cgps_tile_stream.h).
+    record by its own cgps_shard_reduce on its own HIP stream, and the ONE all-gather then carries S
+    records per rank; the finish kernel takes the world * S records in order.  Default: one record per
+    rank -- measured on one GPU (profiles/r03_shard_2p21.json and bench.py's extras), two sub-shards of a
+    2^21-row shard on two streams take 184 us against 136-141 us for the one launch: the launches do not
+    overlap, each wants the whole chip.
     `ops` is the pair of device steps (default: the HIP library); tests inject a dense-algebra
     stand-in to exercise the collective plumbing on CPU/gloo.  `gather(send, recv)` replaces the
     collective (tests play the ranks one after the other on one GPU)."""
@@ -178,6 +178,12 @@ class HipSolveOps:
     def solve(dec, y):
         from . import cyclic_reduction as cr
         return cr.solve(dec, y)
+
+    @staticmethod
+    def factor_solve(Rs, Os, y):
+        """factor and solve together: the forward substitution rides along in the factorisation (cgps_decompose_solve)"""
+        from . import cyclic_reduction as cr
+        return cr.decompose_solve(Rs, Os, y)
 
     @staticmethod
     def inverse_blocks(dec):
@@ -331,8 +337,11 @@ class ShardedPosterior:
             R_loc, O_loc, y_loc = self.Rs.clone(), self.Os, y.clone()
         R_loc[-1] += dR
         y_loc[-1] += dy
-        dec = self.solve_ops.factor(R_loc.contiguous(), O_loc.contiguous())
-        mean = self.solve_ops.solve(dec, y_loc.contiguous())
+        if hasattr(self.solve_ops, "factor_solve"):
+            dec, mean = self.solve_ops.factor_solve(R_loc.contiguous(), O_loc.contiguous(), y_loc.contiguous())
+        else:
+            dec = self.solve_ops.factor(R_loc.contiguous(), O_loc.contiguous())
+            mean = self.solve_ops.solve(dec, y_loc.contiguous())
         Sd, So = self.solve_ops.inverse_blocks(dec)
         if r > 0:
             return mean[1:], Sd[1:], So

@@ -58,7 +58,8 @@ enum {
   CGPS_OP_SOLVE = 4,
   CGPS_OP_LOGDET_FACTOR = 5,
   CGPS_OP_INVERSE_BLOCKS = 6,
-  CGPS_OP_MAHAL_LOGDET_LEVELWISE = 7
+  CGPS_OP_MAHAL_LOGDET_LEVELWISE = 7,
+  CGPS_OP_DECOMPOSE_SOLVE = 8
 };
 
 #define CGPS_MAX_LEVELS 64
@@ -112,6 +113,16 @@ int cgps_backsolve(const void* Dp, const void* Fp, const void* Gp, int64_t N, in
 /* solve(decomp, y) -> J^-1 y                                   cyclic_reduction.py:441-444 */
 int cgps_solve(const void* Dp, const void* Fp, const void* Gp, int64_t N, int d, int dtype, int nrhs,
                const void* y, void* x, void* ws, size_t ws_bytes, void* stream);
+
+/* decompose(Rs, Os) AND solve(decomp, y) in one call, for callers that factor and solve together
+ * (compute_insample_posterior, models.py:288-292; the backward of mahal_and_det): the factor comes out as from
+ * cgps_decompose, xcrr[N][d] = halfsolve(decomp, y) in CRR layout, x[N][d] = J^-1 y.  The forward substitution of
+ * y rides along in the first pass of the factorisation, so the forward sweep proper starts three levels down and
+ * never reads the factor blocks of those levels (7/8 of the factor): the factor is read once, not twice.
+ * Workspace: cgps_workspace_bytes(N, d, dtype, CGPS_OP_DECOMPOSE_SOLVE). */
+int cgps_decompose_solve(const void* Rs, const void* Os, const void* y, int64_t N, int d, int dtype,
+                         void* Dp, void* Fp, void* Gp, void* xcrr, void* x, void* ws, size_t ws_bytes, int* info,
+                         void* stream);
 
 /* det(decomp) -> log|J| = 2 sum log diag(D)                    cyclic_reduction.py:447-458 */
 int cgps_logdet_factor(const void* Dp, int64_t N, int d, int dtype,

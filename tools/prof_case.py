@@ -24,7 +24,7 @@ import cyclic_gps.cyclic_reduction as cr  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--op", default="mahal_and_det",
-                    choices=["mahal_and_det", "decompose", "solve", "halfsolve", "det", "inverse_blocks"])
+                    choices=["mahal_and_det", "decompose", "solve", "halfsolve", "det", "inverse_blocks", "decompose_solve"])
     ap.add_argument("--nrhs", type=int, default=1, help="right-hand-side columns for solve / halfsolve")
     ap.add_argument("--rows", type=int, default=2 ** 20)
     ap.add_argument("--d", type=int, default=4)
@@ -43,6 +43,7 @@ def main():
         "halfsolve": lambda: cr.halfsolve(dec, b),
         "det": lambda: cr.det(dec),
         "inverse_blocks": lambda: cr.inverse_blocks(dec),
+        "decompose_solve": lambda: cr.decompose_solve(Rs, Os, b),
     }[a.op]
     fn()
     torch.cuda.synchronize()
