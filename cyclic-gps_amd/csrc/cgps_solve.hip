@@ -340,7 +340,7 @@ int run_halfsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const 
     const int64_t nsurv = n >> P.lv[p].nlev;
     T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D][MC] surviving rows, then [g][D][MC] owed panels
     T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * PW : nullptr;
-    hipLaunchKernelGGL((cgps::halfsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT), lds, st, Dp, Fp, Gp, P.lv[p],
+    hipLaunchKernelGGL((cgps::halfsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * cgps::solve_m_col_splits<MC>()), lds, st, Dp, Fp, Gp, P.lv[p],
                        owed_in, n_owed, spt_in, y, ld, n, w, xcrr, ld_x, yout, owed_out, partial + 2 * *pb);
     *pb += g;
     y = yout;
@@ -368,7 +368,7 @@ int run_backsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const 
   for (int p = P.np - 1; p >= 0; --p) {
     const int64_t n = P.rows[p], g = (n + TS - 1) / TS;
     T* X = (p == 0) ? x : bufs[p & 1];
-    hipLaunchKernelGGL((cgps::backsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT), lds, st, Dp, Fp, Gp, P.lv[p],
+    hipLaunchKernelGGL((cgps::backsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * cgps::solve_m_col_splits<MC>()), lds, st, Dp, Fp, Gp, P.lv[p],
                        b, ld_b, xc, n, w, X, (p == 0) ? ld_o : MC);
     xc = X;
   }

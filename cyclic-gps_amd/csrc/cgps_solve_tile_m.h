@@ -16,8 +16,15 @@
 namespace cgps {
 
 template <int MC> constexpr int solve_m_tile_log2() { return MC <= 2 ? 9 : (MC <= 4 ? 8 : 7); }
+// Eight columns: the 128-row tile has 64 threads' worth of eliminations, ONE wave per workgroup, and the LDS tile lets
+// four or five of them share a CU -- barely more than a wave per SIMD, every latency of a level exposed (2.7 TB/s).
+// The panel's columns are therefore split over CS = 2 waves of the workgroup: wave c takes columns [4c, 4c + 4) of
+// every row, both read the same factor blocks (the second read hits L1), twice the waves per SIMD for the same LDS.
+template <int MC> constexpr int solve_m_col_splits() { return MC >= 8 ? 2 : 1; }   // measured: 4 splits 760 us, 2 splits for four columns 433 against 400 us
 
-template <typename T, int D, int MC>
+// A thread's panel: D x MC values, columns [c0, c0 + MC) of a dense [D][LDC] panel in LDS / in the workspace (LDC = MC:
+// the whole panel).
+template <typename T, int D, int MC, int LDC = MC>
 struct Panel {
   T v[D][MC];
   __device__ __forceinline__ void zero() {
@@ -43,8 +50,28 @@ struct Panel {
   // global, dense [d][MC] (ld == MC, every column real): 16-byte vectors when a panel row is a
   // whole number of them (then every row is 16-byte aligned too), contiguous scalars otherwise
   static constexpr bool VEC = (D * MC) % Vec16<T>::N == 0;
+  static constexpr bool ROWVEC = MC % Vec16<T>::N == 0 && LDC % Vec16<T>::N == 0;     // sub-panel: whole vectors per row
   __device__ __forceinline__ void load_dense(const T* __restrict__ p) {
     T* flat = &v[0][0];
+    if constexpr (LDC != MC) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        if constexpr (ROWVEC) {
+          constexpr int VN = Vec16<T>::N;
+          using V = typename Vec16<T>::type;
+#pragma unroll
+          for (int g = 0; g < MC / VN; ++g) {
+            const V x = *reinterpret_cast<const V*>(p + (size_t)i * LDC + g * VN);
+            const T* e = reinterpret_cast<const T*>(&x);
+#pragma unroll
+            for (int u = 0; u < VN; ++u) v[i][g * VN + u] = e[u];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < MC; ++c) v[i][c] = p[(size_t)i * LDC + c];
+        }
+      }
+    } else
     if constexpr (VEC) {
       constexpr int VN = Vec16<T>::N;
       using V = typename Vec16<T>::type;
@@ -63,6 +90,26 @@ struct Panel {
   }
   __device__ __forceinline__ void store_dense(T* __restrict__ p) const {
     const T* flat = &v[0][0];
+    if constexpr (LDC != MC) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        if constexpr (ROWVEC) {
+          constexpr int VN = Vec16<T>::N;
+          using V = typename Vec16<T>::type;
+#pragma unroll
+          for (int g = 0; g < MC / VN; ++g) {
+            V x;
+            T* e = reinterpret_cast<T*>(&x);
+#pragma unroll
+            for (int u = 0; u < VN; ++u) e[u] = v[i][g * VN + u];
+            *reinterpret_cast<V*>(p + (size_t)i * LDC + g * VN) = x;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < MC; ++c) p[(size_t)i * LDC + c] = v[i][c];
+        }
+      }
+    } else
     if constexpr (VEC) {
       constexpr int VN = Vec16<T>::N;
       using V = typename Vec16<T>::type;
@@ -80,25 +127,26 @@ struct Panel {
       for (int i = 0; i < D * MC; ++i) p[i] = flat[i];
     }
   }
-  // either form, chosen per call (wave-uniform)
-  __device__ __forceinline__ void load_any(const T* __restrict__ p, int ld, int w) {
-    if (ld == MC && w == MC) load_dense(p); else load(p, ld, w);
+  // either form, chosen per call (wave-uniform); p points at this thread's first column c0, w counts the valid
+  // columns of the WHOLE panel
+  __device__ __forceinline__ void load_any(const T* __restrict__ p, int ld, int w, int c0 = 0) {
+    if (ld == LDC && w == LDC) load_dense(p); else load(p, ld, w - c0);
   }
-  __device__ __forceinline__ void store_any(T* __restrict__ p, int ld, int w) const {
-    if (ld == MC && w == MC) store_dense(p); else store(p, ld, w);
+  __device__ __forceinline__ void store_any(T* __restrict__ p, int ld, int w, int c0 = 0) const {
+    if (ld == LDC && w == LDC) store_dense(p); else store(p, ld, w - c0);
   }
-  // LDS, dense [d][MC]
+  // LDS, dense [d][LDC] (p points at the thread's first column)
   __device__ __forceinline__ void lds_load(const T* p) {
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int c = 0; c < MC; ++c) v[i][c] = p[i * MC + c];
+      for (int c = 0; c < MC; ++c) v[i][c] = p[i * LDC + c];
   }
   __device__ __forceinline__ void lds_store(T* p) const {
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-      for (int c = 0; c < MC; ++c) p[i * MC + c] = v[i][c];
+      for (int c = 0; c < MC; ++c) p[i * LDC + c] = v[i][c];
   }
   __device__ __forceinline__ void sub(const Panel& o) {
 #pragma unroll
@@ -183,31 +231,34 @@ constexpr size_t solve_m_lds_bytes() {
 // ---- forward sweep (cf. halfsolve_tile_kernel) ---------------------------------------------------
 // y_in [n][d][ld_y]; xcrr [N][d][ld_x] (CRR layout); y_out / owed_in / owed_out: workspace, ld = MC.
 template <typename T, int D, int MC>
-__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_tile_m_kernel(
+__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2 * solve_m_col_splits<MC>()) void halfsolve_tile_m_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
     const T* __restrict__ owed_in, int64_t n_owed, int spt_in, const T* __restrict__ y_in, int ld_y, int64_t n, int w,
     T* __restrict__ xcrr, int ld_x, T* __restrict__ y_out, T* __restrict__ owed_out, double* __restrict__ partial) {
   constexpr int DD = D * D, TS = 1 << solve_m_tile_log2<MC>(), NT = TS / 2, PW = D * MC;
-  using P = Panel<T, D, MC>;
+  constexpr int CS = solve_m_col_splits<MC>(), MS = MC / CS, NTT = NT * CS;      // threads of a column split x splits
+  using P = Panel<T, D, MS, MC>;
   extern __shared__ __attribute__((aligned(16))) char solve_smem[];
   T* ys = reinterpret_cast<T*>(solve_smem);                                   // [TS][D][MC]
   T* owed = ys + (size_t)TS * PW;                                             // [D][MC]: sum_j G_j x_j of the tile's first rows
   double* red = reinterpret_cast<double*>(owed + PW);
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x % NT, c0 = (threadIdx.x / NT) * MS;             // elimination index base / first column
   const int64_t row0 = (int64_t)blockIdx.x * TS;
   const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
+  ys += c0;
+  owed += c0;
   for (int r = tid; r < n0; r += NT) {
     P v;
-    v.load_any(y_in + (row0 + r) * (size_t)D * ld_y, ld_y, w);
+    v.load_any(y_in + (row0 + r) * (size_t)D * ld_y + c0, ld_y, w, c0);
     const int64_t wn = row0 + r + 1;
     if (owed_in != nullptr && wn % spt_in == 0 && wn / spt_in < n_owed) {     // the last survivor of a tile of the previous pass
       P o;
-      o.load_dense(owed_in + (wn / spt_in) * (size_t)PW);
+      o.load_dense(owed_in + (wn / spt_in) * (size_t)PW + c0);
       v.sub(o);
     }
     v.lds_store(ys + (size_t)r * PW);
   }
-  for (int i = tid; i < PW; i += NT) owed[i] = T(0);
+  for (int i = threadIdx.x; i < PW; i += NTT) (owed - c0)[i] = T(0);
   __syncthreads();
   double mah = 0.0, zero = 0.0;
   int nj = n0;
@@ -219,7 +270,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
     chol_from_dense<T, D>(L, c);
     x.fwd(c);
     x.lds_store(ys + (size_t)(((2 * k + 1) << j) - 1) * PW);
-    x.store_any(xcrr + (lv.offD[j] + g0 + k) * (size_t)D * ld_x, ld_x, w);
+    x.store_any(xcrr + (lv.offD[j] + g0 + k) * (size_t)D * ld_x + c0, ld_x, w, c0);
     mah += x.sumsq();
     if (k == 0 && g0 >= 1) {                             // the previous tile's last row is this row's left neighbour
       T G[D][D];
@@ -264,13 +315,13 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
     for (int r = tid; r < nj; r += NT) {
       P v;
       v.lds_load(ys + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
-      v.store_dense(y_out + ((size_t)blockIdx.x * spt_out + r) * PW);
+      v.store_dense(y_out + ((size_t)blockIdx.x * spt_out + r) * PW + c0);
     }
   }
   if (owed_out != nullptr)
-    for (int i = tid; i < PW; i += NT) owed_out[(size_t)blockIdx.x * PW + i] = owed[i];
-  block_sum2<NT>(mah, zero, red);
-  if (tid == 0 && partial != nullptr) {
+    for (int i = threadIdx.x; i < PW; i += NTT) owed_out[(size_t)blockIdx.x * PW + i] = (owed - c0)[i];
+  block_sum2<NTT>(mah, zero, red);
+  if (threadIdx.x == 0 && partial != nullptr) {
     partial[2 * (size_t)blockIdx.x] = mah;
     partial[2 * (size_t)blockIdx.x + 1] = 0.0;
   }
@@ -279,24 +330,26 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void halfsolve_
 // ---- backward sweep (cf. backsolve_tile_kernel) --------------------------------------------------
 // b [N][d][ld_b] in CRR layout; x_coarse: workspace (ld = MC), nullptr for the top pass; x_out [n][d][ld_o].
 template <typename T, int D, int MC>
-__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_tile_m_kernel(
+__global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2 * solve_m_col_splits<MC>()) void backsolve_tile_m_kernel(
     const T* __restrict__ Dp, const T* __restrict__ Fp, const T* __restrict__ Gp, PassLevels lv,
     const T* __restrict__ b, int ld_b, const T* __restrict__ x_coarse, int64_t n, int w, T* __restrict__ x_out, int ld_o) {
   constexpr int DD = D * D, TS = 1 << solve_m_tile_log2<MC>(), NT = TS / 2, PW = D * MC;
-  using P = Panel<T, D, MC>;
+  constexpr int CS = solve_m_col_splits<MC>(), MS = MC / CS;
+  using P = Panel<T, D, MS, MC>;
   extern __shared__ __attribute__((aligned(16))) char solve_smem[];
   T* xs = reinterpret_cast<T*>(solve_smem);                                   // [TS][D][MC]
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x % NT, c0 = (threadIdx.x / NT) * MS;
   const int64_t row0 = (int64_t)blockIdx.x * TS;
   const int n0 = (int)((n - row0) < TS ? (n - row0) : TS);
+  xs += c0;
   P xleft;                                               // x of the previous tile's last row
   xleft.zero();
   if (x_coarse != nullptr) {                             // solution of the rows that survived this pass's levels
     const int spt = TS >> lv.nlev;
-    if (blockIdx.x > 0) xleft.load_dense(x_coarse + ((size_t)blockIdx.x * spt - 1) * PW);
+    if (blockIdx.x > 0) xleft.load_dense(x_coarse + ((size_t)blockIdx.x * spt - 1) * PW + c0);
     for (int r = tid; r < (n0 >> lv.nlev); r += NT) {
       P v;
-      v.load_dense(x_coarse + ((size_t)blockIdx.x * spt + r) * PW);
+      v.load_dense(x_coarse + ((size_t)blockIdx.x * spt + r) * PW + c0);
       v.lds_store(xs + (size_t)(((r + 1) << lv.nlev) - 1) * PW);
     }
   }
@@ -310,7 +363,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_
       for (int k = tid; k < ne; k += NT) {
         T M[D][D];
         P r, xo;
-        r.load_any(b + (lv.offD[j] + g0 + k) * (size_t)D * ld_b, ld_b, w);
+        r.load_any(b + (lv.offD[j] + g0 + k) * (size_t)D * ld_b + c0, ld_b, w, c0);
         if (2 * k + 1 < nj) {
           load_block<T, D>(Fp + (lv.offF[j] + g0 + k) * DD, M);
           xo.lds_load(xs + (size_t)(((2 * k + 2) << j) - 1) * PW);
@@ -337,7 +390,7 @@ __global__ __launch_bounds__((1 << solve_m_tile_log2<MC>()) / 2) void backsolve_
   for (int r = tid; r < n0; r += NT) {
     P v;
     v.lds_load(xs + (size_t)r * PW);
-    v.store_any(x_out + (row0 + r) * (size_t)D * ld_o, ld_o, w);
+    v.store_any(x_out + (row0 + r) * (size_t)D * ld_o + c0, ld_o, w, c0);
   }
 }
 
