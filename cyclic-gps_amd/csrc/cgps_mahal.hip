@@ -3,6 +3,7 @@
 // enqueues kernels on the caller's stream: nothing here allocates, copies to the host or synchronises.
 #include "cgps_host.h"
 #include "cgps_tile.h"
+#include "cgps_boundary.h"
 
 using namespace cgps_host;
 
@@ -105,6 +106,38 @@ int cgps_leg_mahal_logdet_pair(const void* ts, const void* G, const void* A, con
     if (rc == -1) return fail(CGPS_ERR_ARG, "workspace too small for cgps_leg_mahal_logdet_pair (twice cgps_mahal_logdet's, each rounded up to 256 bytes)");
     if (rc == -2) return fail(CGPS_ERR_UNSUPPORTED, "cgps_leg_mahal_logdet_pair: not built for this block size (d = 8, fp64 d = 6) or CGPS_NO_FOLD=1");
     return check_launch("LEG tile reduction (pair)");
+  });
+}
+
+int cgps_boundary_solve(const void* records, size_t record_stride_bytes, int64_t P, int d, int dtype, void* xsep, int* info,
+                        void* stream) {
+  if (P < 1 || d < 1 || !records || !xsep || !info) return fail(CGPS_ERR_ARG, "cgps_boundary_solve: null pointer or P < 1");
+  if (P > cgps::BOUNDARY_MAX_P) return fail(CGPS_ERR_UNSUPPORTED, "cgps_boundary_solve: P = %lld records, at most %d", (long long)P, cgps::BOUNDARY_MAX_P);
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if (record_stride_bytes % sizeof(T) != 0 || record_stride_bytes < cgps::RecordLayout<T, D>::STRIDE * sizeof(T))
+      return fail(CGPS_ERR_ARG, "cgps_boundary_solve: bad record stride");
+    hipLaunchKernelGGL((cgps::boundary_solve_kernel<T, D>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const T*)records,
+                       (int64_t)(record_stride_bytes / sizeof(T)), (int)P, (T*)xsep, info);
+    return check_launch("boundary solve");
+  });
+}
+
+int cgps_boundary_recursions(const void* records, size_t record_stride_bytes, int64_t P, int64_t rank, int d, int dtype,
+                             void* out, int* info, void* stream) {
+  if (P < 1 || rank < 0 || rank >= P || d < 1 || !records || !out || !info)
+    return fail(CGPS_ERR_ARG, "cgps_boundary_recursions: null pointer, P < 1 or rank outside 0..P-1");
+  return dispatch(dtype, d, [&](auto t, auto dc) {
+    using T = decltype(t);
+    constexpr int D = decltype(dc)::value;
+    if (record_stride_bytes % sizeof(T) != 0 || record_stride_bytes < cgps::RecordLayout<T, D>::STRIDE * sizeof(T))
+      return fail(CGPS_ERR_ARG, "cgps_boundary_recursions: bad record stride");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(info, 0, sizeof(int), st);
+    hipLaunchKernelGGL((cgps::boundary_recursions_kernel<T, D>), dim3(1), dim3(128), 0, st, (const T*)records,
+                       (int64_t)(record_stride_bytes / sizeof(T)), (int)P, (int)rank, (T*)out, info);
+    return check_launch("boundary recursions");
   });
 }
 

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "cgps_last_error": (ctypes.c_char_p, []),
     "cgps_profile_next_call": (_int, [_vp, _vp]),
     "cgps_reset_counters": (_int, [_vp]),
+    "cgps_boundary_solve": (_int, [_vp, _sz, _i64, _int, _int, _vp, _vp, _vp]),
+    "cgps_boundary_recursions": (_int, [_vp, _sz, _i64, _i64, _int, _int, _vp, _vp, _vp]),
     "cgps_level_layout": (_int, [_i64, ctypes.POINTER(_int)] + [ctypes.POINTER(_i64)] * 4),
     "cgps_workspace_bytes": (_int, [_i64, _int, _int, _int, ctypes.POINTER(_sz)]),
     "cgps_mahal_logdet": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _sz, _vp, _vp, _vp]),

@@ -166,6 +166,28 @@ def boundary_system(recv, world, rec_bytes, msg_bytes, d, dtype):
     return Rb.contiguous(), Cs[1:].contiguous(), yb.contiguous()
 
 
+def hip_boundary_solve(recv, world, msg_bytes, d, dtype):
+    """x at every shard's last row, [world, d], from the gathered records: ONE launch (cgps_boundary_solve) instead of
+    boundary_system's batched torch ops plus a world-row decompose + solve."""
+    xsep = torch.empty(world, d, dtype=dtype, device=recv.device)
+    info = torch.zeros(1, dtype=torch.int32, device=recv.device)
+    _hip.check(_hip.lib().cgps_boundary_solve(_hip.ptr(recv), msg_bytes, world, d, _hip.dtype_code(dtype), _hip.ptr(xsep),
+                                              _hip.ptr(info), _hip.stream_ptr()))
+    return xsep
+
+
+def hip_boundary_recursions(recv, world, msg_bytes, d, dtype, rank):
+    """boundary_recursions() as ONE launch (cgps_boundary_recursions): (Pa, pa, dR, dy), Pa / pa None on rank 0."""
+    out = torch.empty(2 * d * d + 2 * d, dtype=dtype, device=recv.device)
+    info = torch.zeros(1, dtype=torch.int32, device=recv.device)
+    _hip.check(_hip.lib().cgps_boundary_recursions(_hip.ptr(recv), msg_bytes, world, rank, d, _hip.dtype_code(dtype),
+                                                   _hip.ptr(out), _hip.ptr(info), _hip.stream_ptr()))
+    dd = d * d
+    Pa, pa = out[:dd].view(d, d), out[dd:dd + d]
+    dR, dy = out[dd + d:2 * dd + d].view(d, d), out[2 * dd + d:]
+    return (None, None, dR, dy) if rank == 0 else (Pa, pa, dR, dy)
+
+
 class HipSolveOps:
     """Block-tridiagonal solves of the sharded solve through the drop-in module (the HIP kernels)."""
 
@@ -213,6 +235,7 @@ class ShardedSolve:
         self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
         self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
         self.solve_ops = solve_ops if solve_ops is not None else HipSolveOps
+        self._hip_boundary = ops is None and world <= 64            # the library's record layout: one launch for the separators
         self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
         dev = Rs.device
         self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
@@ -234,8 +257,11 @@ class ShardedSolve:
             src = self.recv
         else:
             src = self.send
-        Rb, Ob, yb = boundary_system(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype)
-        x_sep = self.solve_ops.solve(self.solve_ops.factor(Rb, Ob), yb)              # [world, d], same on every rank
+        if self._hip_boundary:
+            x_sep = hip_boundary_solve(src, self.world, self.msg_bytes, d, self.Rs.dtype)
+        else:
+            Rb, Ob, yb = boundary_system(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype)
+            x_sep = self.solve_ops.solve(self.solve_ops.factor(Rb, Ob), yb)          # [world, d], same on every rank
         x = torch.empty_like(y)
         x[-1] = x_sep[self.rank]
         if n > 1:
@@ -309,6 +335,7 @@ class ShardedPosterior:
         self.n_loc, self.d = Rs.shape[0], Rs.shape[1]
         self.ops = ops if ops is not None else HipShardOps(self.n_loc, self.d, Rs.dtype, Rs.device)
         self.solve_ops = solve_ops if solve_ops is not None else HipSolveOps
+        self._hip_boundary = ops is None
         self.rec_bytes, self.msg_bytes = message_layout(self.d, Rs.dtype) if ops is None else ops.layout()
         dev = Rs.device
         self.send = torch.zeros(self.msg_bytes, dtype=torch.uint8, device=dev)
@@ -328,7 +355,10 @@ class ShardedPosterior:
             src = self.recv
         else:
             src = self.send
-        Pa, pa, dR, dy = boundary_recursions(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype, r)
+        if self._hip_boundary:
+            Pa, pa, dR, dy = hip_boundary_recursions(src, self.world, self.msg_bytes, d, self.Rs.dtype, r)
+        else:
+            Pa, pa, dR, dy = boundary_recursions(src, self.world, self.rec_bytes, self.msg_bytes, d, self.Rs.dtype, r)
         if r > 0:
             R_loc = torch.cat([Pa[None], self.Rs])
             O_loc = torch.cat([self.O_left[None], self.Os])

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CGPS_VERSION 310
+#define CGPS_VERSION 320
 
 enum { CGPS_F32 = 0, CGPS_F64 = 1 };
 
@@ -217,6 +217,18 @@ int cgps_shard_reduce(const void* Rs, const void* Os, const void* x, const void*
 int cgps_finish_records(const void* records, size_t record_stride_bytes, const double* partials,
                         size_t partial_stride_bytes, int64_t P, int64_t rows_per_shard, int64_t N_total, int d,
                         int dtype, double* out2, int* info, void* stream);
+
+/* The small systems a sharded SOLVE needs from the gathered records (cyclic_gps/sharded.py), one launch each:
+ * cgps_boundary_solve: x at every shard's last row, xsep[P][d] -- the P-row block-tridiagonal system of the shards' last
+ *   rows (R_w = Rs_w + dRa_{w+1}, y_w = ys_w + dya_{w+1}, J[w+1, w] = Cs_{w+1}) solved by block Cholesky; P <= 64;
+ *   info: 0 or 1 + the first row whose pivot block is not positive definite.
+ * cgps_boundary_recursions: what the rest of the system leaves on rank's two ends, out = [Pa (d*d) | pa (d) | dR (d*d) | dy (d)]:
+ *   (Pa, pa) = diagonal block and right-hand side of the PREVIOUS shard's last row once every row left of it has been
+ *   eliminated (zeros for rank 0), (dR, dy) = what eliminating every row right of rank's last row adds to that row. */
+int cgps_boundary_solve(const void* records, size_t record_stride_bytes, int64_t P, int d, int dtype, void* xsep,
+                        int* info, void* stream);
+int cgps_boundary_recursions(const void* records, size_t record_stride_bytes, int64_t P, int64_t rank, int d, int dtype,
+                             void* out, int* info, void* stream);
 
 /* The one-launch forms of cgps_mahal_logdet / cgps_shard_reduce hand records from workgroup to workgroup inside the
  * launch through arrival counters in the library's own device memory.  Every completed launch leaves them at zero;

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(_hip.exported_symbols()) == declared
-    assert _hip.lib().cgps_version() == 310
+    assert _hip.lib().cgps_version() == 320
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 6, 31, 32, 33, 502, 1024, 2 ** 20, 2 ** 24 + 5])

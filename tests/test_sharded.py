@@ -377,3 +377,44 @@ def test_sharded_posterior_config4_shape():
     JS = Rl @ Sd[:-1] + Ol @ So[:-1].transpose(-1, -2) + Os[lo:hi - 1].transpose(-1, -2) @ So[1:]
     eye = torch.eye(d, dtype=JS.dtype, device=JS.device)
     assert float((JS - eye).abs().max()) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dtype", [(1, torch.float64), (3, torch.float64), (4, torch.float64), (5, torch.float64),
+                                     (8, torch.float64), (4, torch.float32), (8, torch.float32)],
+                         ids=lambda p: str(p).replace("torch.", ""))
+@pytest.mark.parametrize("parts", [1, 2, 3, 8, 17, 64])
+def test_boundary_kernels_against_the_torch_restatement(d, dtype, parts):
+    """cgps_boundary_solve / cgps_boundary_recursions (one launch each) against boundary_system + a dense solve and
+    against boundary_recursions (batched torch ops), on the records of a real system cut into `parts` shards; the
+    separator values also against the planted solution."""
+    n = parts * 37 + 5
+    Rs, Os, b, x_true, _ = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=parts)
+    bounds = [sharded.shard_bounds(n, parts, r) for r in range(parts)]
+    rec_bytes, msg_bytes = sharded.message_layout(d, dtype)
+    recv = torch.zeros(parts * msg_bytes, dtype=torch.uint8, device="cuda")
+    for r, (lo, hi) in enumerate(bounds):
+        ops = sharded.HipShardOps(hi - lo, d, dtype, torch.device("cuda"))
+        ops.shard_reduce(Rs[lo:hi].contiguous(), Os[lo:hi - 1].contiguous(), b[lo:hi].contiguous(),
+                         Os[lo - 1].contiguous() if lo else None, recv[r * msg_bytes:(r + 1) * msg_bytes], rec_bytes)
+    tol = 1e-9 if dtype == torch.float64 else 2e-3
+    x_sep = sharded.hip_boundary_solve(recv, parts, msg_bytes, d, dtype)
+    last = torch.tensor([hi - 1 for _, hi in bounds], device="cuda")
+    assert float((x_sep.double() - x_true[last].double()).abs().max()) <= tol
+    Rb, Ob, yb = sharded.boundary_system(recv, parts, rec_bytes, msg_bytes, d, dtype)
+    dense = torch.zeros(parts * d, parts * d, dtype=torch.float64, device="cuda")
+    for w in range(parts):
+        dense[w * d:(w + 1) * d, w * d:(w + 1) * d] = Rb[w].double()
+        if w + 1 < parts:
+            dense[(w + 1) * d:(w + 2) * d, w * d:(w + 1) * d] = Ob[w].double()
+            dense[w * d:(w + 1) * d, (w + 1) * d:(w + 2) * d] = Ob[w].double().T
+    ref = torch.linalg.solve(dense, yb.double().reshape(-1)).reshape(parts, d)
+    assert float((x_sep.double() - ref).abs().max()) <= tol
+    for r in sorted({0, parts // 2, parts - 1}):
+        Pa, pa, dR, dy = sharded.hip_boundary_recursions(recv, parts, msg_bytes, d, dtype, r)
+        Pa0, pa0, dR0, dy0 = sharded.boundary_recursions(recv, parts, rec_bytes, msg_bytes, d, dtype, r)
+        for a, a0 in ((Pa, Pa0), (pa, pa0), (dR, dR0), (dy, dy0)):
+            if a0 is None:
+                assert a is None
+            else:
+                assert float((a.double() - a0.double()).abs().max()) <= tol * max(1.0, float(a0.abs().max()))
