@@ -243,16 +243,6 @@ def _pair(a, b):
     return a.reshape(a.shape[0], a.shape[1], -1) @ b.reshape(b.shape[0], b.shape[1], -1).transpose(-1, -2)
 
 
-_side_streams = {}
-
-
-def _side_stream(device):
-    s = _side_streams.get(device)
-    if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
-    return s
-
-
 class _MahalLogdetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Rs, Os, x):
