@@ -3,6 +3,8 @@ bidiagonal, so log|J| and the planted solution are known exactly -- tests/_util.
 
 Sizes are drawn around every switch point of the kernels (rows per lane 1 / 4 / 8 / 16, one or
 two workgroups per CU, record passes, decompose / solve pass structures) and uniformly in between.
+Also: decompose_solve (factor bit-identical to decompose's, planted solution) and, every third case, the LEG
+reductions with the operands assembled in registers against the blocks-in-memory path.
 
   python tools/fuzz_parity.py --seconds 120 [--seed 0] [--d 4 8]
 """
@@ -21,6 +23,7 @@ import torch  # noqa: E402
 
 import _util  # noqa: E402
 import cyclic_gps.cyclic_reduction as cr  # noqa: E402
+from cyclic_gps import leg  # noqa: E402
 
 EDGES = [1, 2, 3, 64, 128, 129, 255, 256, 257, 1024, 4096, 4097, 16384, 32768, 32769, 65536, 65537, 131072,
          262144, 262145, 524288, 524289, 1048576, 1048577, 1 << 21, (1 << 21) + 1]
@@ -71,9 +74,37 @@ def main():
             res[:-1] += Os.transpose(1, 2) @ So
         res -= torch.eye(d, dtype=dtype, device="cuda")
         e5 = float(res.abs().max()) * (1.0 if dtype == torch.float64 else 0.1)
-        err = max(e1, e2 / 10, e3 / 10, e4, e5 / 10)
+        # factor and solve in one call: the same factor bit for bit, the same solution
+        dec2, x2 = cr.decompose_solve(Rs, Os, b)
+        same = all(torch.equal(p_, q_) for k_ in (1, 2, 3) for p_, q_ in zip(dec[k_], dec2[k_]))
+        e6 = float((x2.double() - x_true.double()).abs().max()) if same else float("inf")
+        # the LEG reductions with the operands assembled in registers against the blocks-in-memory path (every third case)
+        e7 = 0.0
+        # (fp32 time stamps cannot resolve gaps of ~0.3 beyond a few thousand rows: the model is an fp64 one)
+        if cases % 3 == 0 and leg.fused_supported(b, torch.empty(d, d, dtype=dtype, device="cuda")) and \
+                (dtype == torch.float64 or n <= 4096):
+            g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+            # (a generator whose symmetric part is well conditioned: with an eigenvalue near zero E ~ I along it, the PEG
+            # blocks are ~1 / that eigenvalue and an fp32 assembly is not positive definite any more -- the model's, not
+            # the kernels', conditioning)
+            Nm = torch.tril(0.2 * torch.randn(d, d, generator=g, dtype=torch.float64), -1) + \
+                torch.diag(0.8 + 0.2 * torch.randn(d, generator=g, dtype=torch.float64).abs())
+            Rm = torch.tril(0.3 * torch.randn(d, d, generator=g, dtype=torch.float64), -1)
+            G = (Nm @ Nm.T + Rm - Rm.T + 1e-5 * torch.eye(d, dtype=torch.float64)).to(dtype).cuda()
+            A = torch.randn(d, 2, generator=g, dtype=torch.float64)
+            A = (0.5 * A @ A.T).to(dtype).cuda()
+            ts = torch.cumsum(0.05 + 0.5 * torch.rand(n, generator=g, dtype=torch.float64), 0).to(dtype).cuda()
+            pRs, pOs = leg.peg_precision(ts, G)
+            m0, l0 = cr.mahal_and_det((pRs + A).double(), pOs.double(), b.double())
+            _, s0 = cr.mahal_and_det(pRs.double(), pOs.double(), torch.zeros_like(b).double())
+            m1, l1, s1 = leg.leg_loglik_reductions(ts, G, A, b)
+            sc = 1.0 if dtype == torch.float64 else 1e-5 / 3e-4 * 30      # fp32 assembly: exponentials and solves in fp32
+            e7 = sc * max(abs(float(l1) - float(l0)) / max(1.0, abs(float(l0))), abs(float(s1) - float(s0)) / max(1.0, abs(float(s0))),
+                          abs(float(m1) - float(m0)) / max(1.0, abs(float(m0))) / 10)
+        err = max(e1, e2 / 10, e3 / 10, e4, e5 / 10, e6 / 10, e7)
         if not err <= tol:
-            print("FAIL", tag, "logdet %.3e mahal %.3e solve %.3e det %.3e inverse %.3e" % (e1, e2, e3, e4, e5), flush=True)
+            print("FAIL", tag, "logdet %.3e mahal %.3e solve %.3e det %.3e inverse %.3e decompose_solve %.3e leg %.3e" % (
+                e1, e2, e3, e4, e5, e6, e7), flush=True)
             sys.exit(1)
         if dtype == torch.float64:
             worst64 = max(worst64, err)
