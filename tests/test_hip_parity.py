@@ -180,7 +180,7 @@ def test_not_positive_definite_raises():
     (2 ** 22, 8, torch.float32, 2e-5),      # BASELINE config 3
     (2 ** 20 + 12345, 4, torch.float64, 1e-10),
     (2 ** 21 + 1, 5, torch.float64, 1e-10),
-    (2 ** 24, 4, torch.float64, 1e-10),     # BASELINE config 4 as ONE system on one GPU (three-launch record path)
+    (2 ** 24, 4, torch.float64, 1e-10),     # BASELINE config 4 as ONE system on one GPU (one launch of long chunks; CGPS_S1_LONG=0: three launches)
     # the one-launch form (record stages inside the stage-1 kernel) for the other block sizes: with the
     # coherent-load hand-off (even d*d in 16-byte vectors) and with the acquire hand-off (the rest)
     (2 ** 19 + 12345, 1, torch.float64, 1e-10),
