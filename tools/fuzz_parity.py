@@ -27,10 +27,13 @@ from cyclic_gps import leg  # noqa: E402
 
 EDGES = [1, 2, 3, 64, 128, 129, 255, 256, 257, 1024, 4096, 4097, 16384, 32768, 32769, 65536, 65537, 131072,
          262144, 262145, 524288, 524289, 1048576, 1048577, 1 << 21, (1 << 21) + 1]
+BIG_EDGES = [1 << 22, 5600003, 1 << 23, 8400001]       # beyond one round of the chip: rows per lane chosen at launch
 
 
 def draw_n(rng, cap):
     r = rng.random()
+    if cap > (1 << 22) and r < 0.04:
+        return min(rng.choice(BIG_EDGES) + rng.choice([-5, 0, 0, 3, 1000]), cap)
     if r < 0.5:
         e = rng.choice(EDGES)
         n = e + rng.choice([-3, -2, -1, 0, 0, 1, 2, 3, 17, -17, 255, -255])
@@ -53,7 +56,7 @@ def main():
     while time.time() - t0 < a.seconds:
         d = rng.choice(a.d if a.d else [1, 2, 3, 4, 4, 4, 5, 6, 7, 8])
         dtype = rng.choice([torch.float64, torch.float64, torch.float32])
-        n = draw_n(rng, (1 << 21) + 300 if d <= 4 else (1 << 19) + 300)
+        n = draw_n(rng, 8500000 if d <= 5 else (1 << 19) + 300)
         Rs, Os, b, x_true, logdet = _util.conditioned_system(n, d, dtype=dtype, device="cuda", seed=rng.randrange(1 << 30))
         mahal_true = float((x_true.double() * b.double()).sum())
         tol = 1e-9 if dtype == torch.float64 else 3e-4
