@@ -8,8 +8,9 @@
 // A lane evaluates its own gap (i) and the gap before it (i-1), so no lane waits for a neighbour
 // and the result does not depend on the launch geometry.
 //
-// exp(A): scaling and squaring around a degree-18 Taylor polynomial in Horner form, ||A||_1 scaled
-// below 1/2 (truncation < 2e-23, the same polynomial degree torch.matrix_exp uses in fp64); the
+// exp(A): scaling and squaring around a Taylor polynomial in Horner form (degree 13 in fp64, 8 in fp32: with ||A||_1
+// <= 1/2 the remainder 0.5^(m+1) / (m+1)! is 7e-16 / 5e-9, below the rounding of the format; rounds 1 and 2 ran
+// degree 18 in both, the degree torch.matrix_exp uses in fp64 for norms up to 5.4), ||A||_1 scaled below 1/2; the
 // two d x d systems are symmetric positive definite (||E||_2 < 1 because G + G^T is positive
 // definite) and go through the Cholesky routines of cgps_math.h.  A gap of zero length makes them
 // singular: reported through `info` (1 + row index), like a non-positive-definite block elsewhere.
@@ -32,6 +33,8 @@ __device__ __forceinline__ void mat_mul(T (&C)[D][D], const T (&A)[D][D], const 
       C[i][j] = s;
     }
 }
+
+template <typename T> constexpr int exp_taylor_degree() { return sizeof(T) == 8 ? 13 : 8; }
 
 // E = exp(A); A is destroyed
 template <typename T, int D>
@@ -57,7 +60,7 @@ __device__ __forceinline__ void mat_exp(T (&E)[D][D], T (&A)[D][D]) {
 #pragma unroll
     for (int j = 0; j < D; ++j) E[i][j] = (i == j) ? T(1) : T(0);
 #pragma unroll 1
-  for (int k = 18; k >= 1; --k) {
+  for (int k = exp_taylor_degree<T>(); k >= 1; --k) {
     T P[D][D];
     mat_mul<T, D>(P, A, E);
     const T rk = T(1) / T(k);
@@ -403,7 +406,7 @@ __device__ __forceinline__ void mat_exp_frechet(T (&E)[D][D], T (&L)[D][D], T (&
 #pragma unroll
     for (int j = 0; j < D; ++j) { E[i][j] = (i == j) ? T(1) : T(0); L[i][j] = T(0); }
 #pragma unroll 1
-  for (int k = 18; k >= 1; --k) {
+  for (int k = exp_taylor_degree<T>(); k >= 1; --k) {
     T P[D][D], Q[D][D], R[D][D];
     mat_mul<T, D>(P, A, E);
     mat_mul<T, D>(Q, dA, E);
