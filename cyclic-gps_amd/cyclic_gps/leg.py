@@ -35,6 +35,19 @@ def _scaled_eye(n, scale, dtype, device):
     return e
 
 
+_llw = {}
+
+
+def _ll_weights(n, dtype, device):
+    """weights of (x (LL^T)^-1 x, log LL^T, k_mahal, k_det, log|Sigma^-1|) in the log-likelihood: -1/2 (quad - k_mahal + n log LLT
+    + k_det - sig) (the n log 2 pi of the observation term is a host constant)"""
+    key = (n, dtype, device)
+    w = _llw.get(key)
+    if w is None:
+        w = _llw[key] = torch.tensor([-0.5, -0.5 * n, 0.5, -0.5, 0.5], dtype=dtype, device=device)
+    return w
+
+
 class LEGMatrices:
     """The four model matrices as the reference registers them (models.py:135-178):
     N [d,d] lower triangular, R [d,d] strictly lower (G uses R - R^T), B [obs,d],
@@ -225,13 +238,19 @@ def log_likelihood(m, ts, xs):
     LLT = m.LLT
     Li = m.inv_of(LLT)
     xl = xs @ Li
-    llt_mahal = (xl * xs).sum()
-    llt_det = (torch.log(2 * math.pi * LLT[0, 0]) if LLT.shape[0] == 1 else torch.logdet(2 * math.pi * LLT)) * xs.shape[0]
     v = (xl @ m.B).contiguous()
     G = m.G
-    if fused_supported(ts, G):
+    n = xs.shape[0]
+    if fused_supported(ts, G) and LLT.shape[0] == 1:
         # the two reductions (prior precision: log-det only; posterior precision: mahal + log-det) never see their blocks
-        # in memory, and run side by side in one launch: they share nothing but ts and G
+        # in memory, and run side by side in one launch: they share nothing but ts and G.  The scalar terms around them
+        # are one product, one log and one weighted sum (N ~ 500 is launch-bound: every small launch is ~2.5 us)
+        k_mahal, k_det, sig_inv_det = leg_loglik_reductions(ts, G, m.B.T @ Li @ m.B, v)
+        terms = torch.stack([torch.dot(xl.reshape(-1), xs.reshape(-1)), torch.log(LLT[0, 0]), k_mahal, k_det, sig_inv_det])
+        return torch.dot(terms, _ll_weights(n, terms.dtype, terms.device)) - 0.5 * n * math.log(2 * math.pi)
+    llt_mahal = (xl * xs).sum()
+    llt_det = (torch.log(2 * math.pi * LLT[0, 0]) if LLT.shape[0] == 1 else torch.logdet(2 * math.pi * LLT)) * n
+    if fused_supported(ts, G):
         k_mahal, k_det, sig_inv_det = leg_loglik_reductions(ts, G, m.B.T @ Li @ m.B, v)
         return -0.5 * ((llt_mahal - k_mahal) + (llt_det + k_det - sig_inv_det))
     Rs, Os = peg_precision(ts, G)
