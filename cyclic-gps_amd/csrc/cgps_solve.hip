@@ -21,8 +21,9 @@ struct SolvePasses {
 
 // deep_tiles: passes of at most this many tiles take the latency-bound kernels (0: never): one
 // 1024-row tile when the rows fit it, 512-row tiles (twice the CUs pulling the factor) otherwise
+// ts_deep / lp_deep (panel sweeps): passes of at most `deep_tiles_m` such tiles take them, in the latency-bound form
 void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts_in = cgps::SOLVE_TS, int lp_in = cgps::SOLVE_LP,
-                 int64_t deep_tiles = 0) {
+                 int64_t deep_tiles = 0, int ts_deep = 0, int lp_deep = 0, int64_t deep_tiles_m = 0) {
   P.np = 0;
   int lvl = 0;
   while (lvl < L.nlevels) {
@@ -33,6 +34,9 @@ void make_passes(const Layout& L, SolvePasses& P, int wide_lp, int ts_in = cgps:
     if (deep_tiles > 0) {
       if (rows <= ts_in) deep = true;
       else if ((rows + ts_in / 2 - 1) / (ts_in / 2) <= deep_tiles) { deep = true; ts = ts_in / 2; lp = lp_in - 1; }
+    }
+    if (ts_deep > 0 && rows < cgps::SOLVE_WIDE_ROWS && (rows + ts_deep - 1) / ts_deep <= deep_tiles_m) {
+      deep = true; ts = ts_deep; lp = lp_deep;
     }
     P.ts[P.np] = ts;
     P.deep[P.np] = deep;
@@ -303,6 +307,13 @@ inline PanelWs panel_ws(int64_t N, int d, size_t s, int mc, int chunks) {
   return w;
 }
 inline int panel_width(int nrhs) { return nrhs <= 2 ? 2 : (nrhs <= 4 ? 4 : 8); }
+// passes of a panel sweep over at most this many 2^TSLD-row tiles (two per CU) take the latency-bound kernels
+// (cgps_solve_tile_m.h: every factor block requested up front); CGPS_NO_DEEP_SOLVE=1: never
+// Measured at 2^20 rows, d = 4 fp64 (tools/prof_case.py --op solve --nrhs m): two columns 285 -> 257 us; four columns
+// 402 -> 451 us, eight 631 -> 740-775 us (a tile's wide panels turn every LDS access of a level into a 64-way bank
+// conflict -- rows of 128 / 256 bytes, lanes a power of two of them apart -- and two such tiles per CU do not cover it;
+// the regular kernels keep four or five smaller tiles per CU in flight): two-column panels only.
+template <int MC> inline int64_t panel_deep_tiles_for() { return (MC <= 2 && deep_solve_enabled()) ? 512 : 0; }
 
 template <typename T, int D, int MC>
 void solve_m_attributes() {
@@ -313,6 +324,13 @@ void solve_m_attributes() {
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_tile_m_kernel<T, D, MC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (cgps::solve_deep_supported<T, D>()) {
+      const int ldsd = (int)cgps::solve_m_deep_lds_bytes<T, D, MC>();
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::halfsolve_deep_m_kernel<T, D, MC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ldsd);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cgps::backsolve_deep_m_kernel<T, D, MC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ldsd);
+    }
     return 1;
   });
 }
@@ -322,10 +340,12 @@ template <typename T, int D, int MC>
 int run_halfsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* y0, int ld_y, int w, T* xcrr, int ld_x,
                         double* partial, int64_t* pb, T* buf0, T* buf1, hipStream_t st) {
   constexpr int TSL = cgps::solve_m_tile_log2<MC>(), TS = 1 << TSL, NT = TS / 2, PW = D * MC;
+  constexpr int TSLD = cgps::solve_m_deep_tile_log2<MC>(), TSD = 1 << TSLD, CS = cgps::solve_m_col_splits<MC>();
+  constexpr bool DEEP = cgps::solve_deep_supported<T, D>();
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL);
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL, 0, DEEP ? TSD : 0, TSLD, panel_deep_tiles_for<MC>());
   solve_m_attributes<T, D, MC>();
   T* bufs[2] = {buf0, buf1};
   const size_t lds = cgps::solve_m_lds_bytes<T, D, MC>();
@@ -335,19 +355,30 @@ int run_halfsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const 
   int64_t n_owed = 0;
   int spt_in = 1;
   for (int p = 0; p < P.np; ++p) {
-    const int64_t n = P.rows[p], g = (n + TS - 1) / TS;
+    const int ts = P.ts[p];
+    const int64_t n = P.rows[p], g = (n + ts - 1) / ts;
     const bool more = (p + 1 < P.np);
     const int64_t nsurv = n >> P.lv[p].nlev;
     T* yout = more ? bufs[p & 1] : nullptr;            // [nsurv][D][MC] surviving rows, then [g][D][MC] owed panels
     T* owed_out = more ? bufs[p & 1] + (nsurv + 1) * PW : nullptr;
-    hipLaunchKernelGGL((cgps::halfsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * cgps::solve_m_col_splits<MC>()), lds, st, Dp, Fp, Gp, P.lv[p],
-                       owed_in, n_owed, spt_in, y, ld, n, w, xcrr, ld_x, yout, owed_out, partial + 2 * *pb);
+    bool launched = false;
+    if constexpr (DEEP) {
+      if (P.deep[p]) {
+        const size_t ldsd = cgps::solve_m_deep_lds_bytes<T, D, MC>();
+        hipLaunchKernelGGL((cgps::halfsolve_deep_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(TSD / 2 * CS), ldsd, st, Dp, Fp, Gp,
+                           P.lv[p], owed_in, n_owed, spt_in, y, ld, n, w, xcrr, ld_x, yout, owed_out, partial + 2 * *pb);
+        launched = true;
+      }
+    }
+    if (!launched)
+      hipLaunchKernelGGL((cgps::halfsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * CS), lds, st, Dp, Fp, Gp, P.lv[p],
+                         owed_in, n_owed, spt_in, y, ld, n, w, xcrr, ld_x, yout, owed_out, partial + 2 * *pb);
     *pb += g;
     y = yout;
     ld = MC;
     owed_in = owed_out;
     n_owed = g;
-    spt_in = TS >> P.lv[p].nlev;
+    spt_in = ts >> P.lv[p].nlev;
     if (spt_in < 1) spt_in = 1;
   }
   return CGPS_OK;
@@ -357,19 +388,32 @@ template <typename T, int D, int MC>
 int run_backsolve_panel(const T* Dp, const T* Fp, const T* Gp, int64_t N, const T* b, int ld_b, int w, T* x, int ld_o,
                         T* buf0, T* buf1, hipStream_t st) {
   constexpr int TSL = cgps::solve_m_tile_log2<MC>(), TS = 1 << TSL, NT = TS / 2;
+  constexpr int TSLD = cgps::solve_m_deep_tile_log2<MC>(), TSD = 1 << TSLD, CS = cgps::solve_m_col_splits<MC>();
+  constexpr bool DEEP = cgps::solve_deep_supported<T, D>();
   Layout L;
   make_layout(N, L);
   SolvePasses P;
-  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL);
+  make_passes(L, P, cgps::SOLVE_LP_WIDE, TS, TSL, 0, DEEP ? TSD : 0, TSLD, panel_deep_tiles_for<MC>());   // (same passes as the forward sweep)
   solve_m_attributes<T, D, MC>();
   T* bufs[2] = {buf0, buf1};
   const size_t lds = cgps::solve_m_lds_bytes<T, D, MC>();
   const T* xc = nullptr;
   for (int p = P.np - 1; p >= 0; --p) {
-    const int64_t n = P.rows[p], g = (n + TS - 1) / TS;
+    const int ts = P.ts[p];
+    const int64_t n = P.rows[p], g = (n + ts - 1) / ts;
     T* X = (p == 0) ? x : bufs[p & 1];
-    hipLaunchKernelGGL((cgps::backsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * cgps::solve_m_col_splits<MC>()), lds, st, Dp, Fp, Gp, P.lv[p],
-                       b, ld_b, xc, n, w, X, (p == 0) ? ld_o : MC);
+    bool launched = false;
+    if constexpr (DEEP) {
+      if (P.deep[p]) {
+        const size_t ldsd = cgps::solve_m_deep_lds_bytes<T, D, MC>();
+        hipLaunchKernelGGL((cgps::backsolve_deep_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(TSD / 2 * CS), ldsd, st, Dp, Fp, Gp,
+                           P.lv[p], b, ld_b, xc, n, w, X, (p == 0) ? ld_o : MC);
+        launched = true;
+      }
+    }
+    if (!launched)
+      hipLaunchKernelGGL((cgps::backsolve_tile_m_kernel<T, D, MC>), dim3((unsigned)g), dim3(NT * CS), lds, st, Dp, Fp, Gp, P.lv[p],
+                         b, ld_b, xc, n, w, X, (p == 0) ? ld_o : MC);
     xc = X;
   }
   return CGPS_OK;
