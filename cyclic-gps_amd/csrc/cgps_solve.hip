@@ -310,9 +310,9 @@ inline int panel_width(int nrhs) { return nrhs <= 2 ? 2 : (nrhs <= 4 ? 4 : 8); }
 // passes of a panel sweep over at most this many 2^TSLD-row tiles (two per CU) take the latency-bound kernels
 // (cgps_solve_tile_m.h: every factor block requested up front); CGPS_NO_DEEP_SOLVE=1: never
 // Measured at 2^20 rows, d = 4 fp64 (tools/prof_case.py --op solve --nrhs m): two columns 285 -> 257 us; four columns
-// 402 -> 451 us, eight 631 -> 740-775 us (a tile's wide panels turn every LDS access of a level into a 64-way bank
-// conflict -- rows of 128 / 256 bytes, lanes a power of two of them apart -- and two such tiles per CU do not cover it;
-// the regular kernels keep four or five smaller tiles per CU in flight): two-column panels only.
+// 402 -> 451 us, eight 631 -> 740-775 us (two 64 KB tiles per CU, each a chain of eight dependent levels on wide panels,
+// against the four or five smaller tiles per CU the regular kernels keep in flight; LDS bank conflicts are not it:
+// padding the panel rows changed nothing, 626 against 635 us): two-column panels only.
 template <int MC> inline int64_t panel_deep_tiles_for() { return (MC <= 2 && deep_solve_enabled()) ? 512 : 0; }
 
 template <typename T, int D, int MC>
