@@ -594,9 +594,29 @@ def main():
     rank_main(args)
 
 
+_JSON_FD = None      # several ranks: the descriptor the ONE JSON line goes to (see rank_main)
+
+
+def _emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def rank_main(args):
-    _load_torch()
+    global _JSON_FD
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # RCCL prints a banner (versions, host name, library path) on STDOUT when a communicator comes up, gloo its
+        # "connected to N peer ranks" lines: with several ranks everything any library prints is sent to stderr, and
+        # stdout carries nothing but rank 0's JSON line
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+    _load_torch()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and not (world == 1 and args.gpus == 1):
@@ -874,7 +894,7 @@ def rank_main(args):
             line["cpu_baseline"] = cpu_baseline(rows, d, dtype)
     else:
         line["cpu_baseline"] = None
-    print(json.dumps(line), flush=True)
+    _emit(line)
 
 
 def _weak_point(args, dev, dtype, d, rank, world, out, barrier):
