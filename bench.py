@@ -716,7 +716,8 @@ def rank_main(args):
         headline_cold = {"ms_per_step": e_cold * 1e3, "GBps": algorithmic_bytes(rows, d, s_el) / e_cold / 1e9,
                          "frac_of_8TBps": algorithmic_bytes(rows, d, s_el) / e_cold / 1e9 / HBM_PEAK_GBPS,
                          "note": "the same %d warm-up + %d timed steps as the FIRST GPU work of the process, before the "
-                                 "secondary measurements; `value` is the same protocol after them" % (args.warmup, args.steps)}
+                                 "secondary measurements; `value` is the same protocol after them and after extras.prewarm_steps "
+                                 "untimed launches of the same step" % (args.warmup, args.steps)}
     extras_early = None
     if not sharded_mode and not args.no_extras and not args.headline_first:
         extras_early = extra_measurements(dev)          # see the module docstring: order of the run
